@@ -1,0 +1,248 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz by running THE REFERENCE ITSELF (build container only).
+
+  python oracle/make_goldens.py [--out tests/golden]
+
+Imports /root/reference (network.resnet38_contrast.Net, tool.torchutils.PolyOptimizer,
+tool.visualization.max_norm) and exec()s the reference's own loop-body text
+(contrast_train.py:129-395 with the hard `.cuda()` calls removed — the recipe of SURVEY.md §8c)
+on procedural weights / inputs from wseg_amd.synth.  Nothing of the reference is copied into
+the repo: only inputs' seeds and the numeric outputs are stored.  Dropout2d masks are injected
+through forward hooks so the reference and the restatement see identical masks.
+"""
+import argparse
+import os
+import random
+import sys
+import textwrap
+import types
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+REF = "/root/reference"
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+from wseg_amd import synth  # noqa: E402
+
+
+def _stub_absent_modules():
+    """cv2 / tensorboardX / torchvision / pydensecrf / imageio are imported at module top by
+    the reference but unused by the functions needed here."""
+    for name in ["cv2", "tensorboardX", "torchvision", "torchvision.transforms", "pydensecrf",
+                 "pydensecrf.densecrf", "pydensecrf.utils", "imageio"]:
+        if name not in sys.modules:
+            try:
+                __import__(name)
+            except Exception:
+                m = types.ModuleType(name)
+                if name == "tensorboardX":
+                    m.SummaryWriter = object
+                if name == "pydensecrf.utils":
+                    m.unary_from_softmax = None
+                sys.modules[name] = m
+
+
+def load_reference():
+    sys.path.insert(0, REF)
+    _stub_absent_modules()
+    import network.resnet38_contrast as R
+    from tool import visualization, torchutils
+    return R, visualization, torchutils
+
+
+def install_masks(model, mask_sets):
+    """Forward hooks that replace each Dropout2d output by input * injected mask.
+    mask_sets: list (one per forward call) of dicts from synth.synthetic_dropout_masks."""
+    state = {"call": 0}
+    sites = {"b6.dropout_2b1": model.b6.dropout_2b1, "b6.dropout_2b2": model.b6.dropout_2b2,
+             "b7.dropout_2b1": model.b7.dropout_2b1, "b7.dropout_2b2": model.b7.dropout_2b2,
+             "dropout7": model.dropout7}
+    handles = []
+    for key, mod in sites.items():
+        def hook(mod_, inp, out, key=key):
+            m = mask_sets[state["call"]][key]
+            return inp[0] * m.view(m.shape[0], m.shape[1], 1, 1)
+        handles.append(mod.register_forward_hook(hook))
+    # advance the mask set after each full forward (dropout7 is the last site)
+    def adv(mod_, inp, out):
+        state["call"] += 1
+    handles.append(model.register_forward_hook(adv))
+    return handles
+
+
+def body_source():
+    lines = open(os.path.join(REF, "contrast_train.py")).read().split("\n")
+    helpers = "\n".join(lines[15:32])                      # :16-32 adaptive_min_pooling_loss, max_onehot
+    body = textwrap.dedent("\n".join(lines[128:395]))      # :129-395
+    body = body.replace(".cuda(non_blocking=True)", "").replace(".cuda()", "")
+    return helpers, body
+
+
+def slc(t, step=8):
+    return t.detach()[..., ::step, ::step].contiguous().numpy()
+
+
+def fwd_golden(R, out_dir, name, n, size, seed, sd):
+    model = R.Net()
+    model.load_state_dict(sd)
+    model.eval()
+    x = synth.synthetic_images(n, size, seed)
+    with torch.no_grad():
+        cam, cam_rv, f_proj, cam_rv_down = model(x)
+    np.savez_compressed(
+        os.path.join(out_dir, name + ".npz"), n=n, size=np.array(size), seed=seed,
+        cam_s=slc(cam, 4), cam_rv_s=slc(cam_rv, 4), f_proj=f_proj.numpy(), cam_rv_down=cam_rv_down.numpy(),
+        cam_argmax=cam.argmax(1).numpy().astype(np.uint8), cam_rv_argmax=cam_rv.argmax(1).numpy().astype(np.uint8),
+        sums=np.array([cam.double().sum().item(), cam_rv.double().sum().item(),
+                       f_proj.double().sum().item(), cam_rv_down.double().sum().item()]))
+    print("wrote", name, [tuple(t.shape) for t in (cam, cam_rv, f_proj, cam_rv_down)])
+
+
+GRAD_KEYS = ["fc8.weight", "fc_proj.weight", "f9.weight", "f8_3.weight", "f8_4.weight",
+             "b7.conv_branch2b1.weight", "b7.conv_branch1.weight", "b6.conv_branch2a.weight",
+             "b5.conv_branch2a.weight", "b4.conv_branch2a.weight", "b4.conv_branch1.weight",
+             "b3.conv_branch2a.weight", "b3_1.conv_branch2b1.weight"]
+
+
+def step_golden(R, visualization, out_dir, name, n, size, seed, sd, py_seed):
+    model = R.Net()
+    model.load_state_dict(sd)
+    model.train()
+    masks = [synth.synthetic_dropout_masks(n, seed * 2 + 0), synth.synthetic_dropout_masks(n, seed * 2 + 1)]
+    install_masks(model, masks)
+    img = synth.synthetic_images(n, size, seed)
+    lab = synth.synthetic_labels(n, seed)
+    helpers, body = body_source()
+    ns = {"torch": torch, "F": F, "np": np, "random": random, "visualization": visualization,
+          "model": model, "pack": (None, img, lab), "args": types.SimpleNamespace(bg_threshold=0.20)}
+    exec(helpers, ns)
+    random.seed(py_seed)
+    exec(body, ns)
+    loss = ns["loss"]
+    loss.backward()
+    scal = {k: float(ns[k]) for k in ["loss", "loss_cls", "loss_er", "loss_ecr", "loss_nce",
+                                      "loss_intra_nce", "loss_cross_nce", "loss_cross_nce2"]}
+    params = dict(model.named_parameters())
+    grads = {}
+    n_with_grad = 0
+    for k, p in params.items():
+        if p.grad is not None:
+            n_with_grad += 1
+    for k in GRAD_KEYS:
+        g = params[k].grad
+        flat = g.reshape(-1)
+        grads["gnorm/" + k] = np.array(g.double().norm().item())
+        grads["gsum/" + k] = np.array(g.double().sum().item())
+        step = max(1, flat.numel() // 4096)
+        grads["gslice/" + k] = flat[::step][:4096].numpy().copy()
+    np.savez_compressed(
+        os.path.join(out_dir, name + ".npz"), n=n, size=size, seed=seed, py_seed=py_seed,
+        n_with_grad=n_with_grad,
+        **{"s/" + k: np.array(v) for k, v in scal.items()},
+        protos1=ns["prototypes1"].numpy(), protos2=ns["prototypes2"].numpy(),
+        pseudo1=ns["pseudo_label1"].numpy().astype(np.uint8), pseudo2=ns["pseudo_label2"].numpy().astype(np.uint8),
+        f1_s=ns["f_proj1"].detach().numpy()[::7].copy(), f2_s=ns["f_proj2"].detach().numpy()[::7].copy(),
+        **grads)
+    print("wrote", name, scal, "params with grad:", n_with_grad)
+
+
+def sgd_golden(torchutils, out_dir):
+    torch.manual_seed(0)
+    g = torch.Generator().manual_seed(5)
+    ps = [torch.randn(7, 5, generator=g), torch.randn(11, generator=g), torch.randn(3, 4, generator=g)]
+    params = [torch.nn.Parameter(p.clone()) for p in ps]
+    opt = torchutils.PolyOptimizer([
+        {"params": [params[0]], "lr": 0.01, "weight_decay": 5e-4},
+        {"params": [params[1]], "lr": 0.02, "weight_decay": 0},
+        {"params": [params[2]], "lr": 0.1, "weight_decay": 5e-4},
+        {"params": [], "lr": 0.2, "weight_decay": 0}], lr=0.01, weight_decay=5e-4, max_step=10)
+    grads = [[torch.randn(p.shape, generator=g) for p in ps] for _ in range(3)]
+    for s in range(3):
+        for p, gr in zip(params, grads[s]):
+            p.grad = gr.clone()
+        if s == 1:
+            params[1].grad = None                  # a skipped parameter
+        opt.step()
+    out = {"momentum": np.array(opt.param_groups[0]["momentum"]), "lr_final": np.array([g_["lr"] for g_ in opt.param_groups])}
+    for i in range(3):
+        out[f"p{i}_init"] = ps[i].numpy()
+        out[f"p{i}_final"] = params[i].detach().numpy()
+        for s in range(3):
+            out[f"g{s}_{i}"] = grads[s][i].numpy()
+    np.savez_compressed(os.path.join(out_dir, "sgd_3steps.npz"), **out)
+    print("wrote sgd_3steps; SGD momentum actually used:", opt.param_groups[0]["momentum"])
+
+
+def topk_pattern_golden(out_dir):
+    out = {}
+    for n in (512, 1024, 4096, 32768):
+        v, i = torch.topk(torch.full((21, n), 0.2)[0:1], 32, dim=-1)
+        out[f"n{n}"] = i[0].numpy()
+        t = torch.full((21, n), 0.2)
+        t[1:] = torch.rand(20, n)
+        out[f"row0_n{n}"] = torch.topk(t, 32, dim=-1)[1][0].numpy()
+    np.savez_compressed(os.path.join(out_dir, "bg_topk_pattern.npz"), **out)
+    print("wrote bg_topk_pattern", {k: v[:4].tolist() for k, v in out.items()})
+
+
+def infer_golden(R, out_dir, sd):
+    model = R.Net()
+    model.load_state_dict(sd)
+    model.eval()
+    H, W = 40, 56
+    lab = torch.zeros(20)
+    lab[[3, 11]] = 1
+    imgs = []
+    for si, s in enumerate([0.5, 1.0, 1.5, 2.0]):
+        hs, ws = int(np.round(H * s)), int(np.round(W * s))
+        im = synth.synthetic_images(1, (hs, ws), 40 + si)
+        imgs += [im, torch.flip(im, dims=[3])]
+    cam_list = []
+    for i, img in enumerate(imgs):
+        with torch.no_grad():                                       # contrast_infer.py:58-66
+            _, cam, _, _ = model(img)
+            cam = F.interpolate(cam[:, 1:, :, :], (H, W), mode="bilinear", align_corners=False)[0]
+            cam = cam.numpy() * lab.clone().view(20, 1, 1).numpy()
+            if i % 2 == 1:
+                cam = np.flip(cam, axis=-1)
+            cam_list.append(cam)
+    lines = open(os.path.join(REF, "contrast_infer.py")).read().split("\n")
+    post = textwrap.dedent("\n".join(lines[74:80]))                 # :75-80
+    pred_src = textwrap.dedent("\n".join(lines[96:98]))             # :97-98
+    ns = {"np": np, "cam_list": cam_list, "args": types.SimpleNamespace(out_cam_pred_alpha=0.26)}
+    exec(post, ns)
+    exec(pred_src, ns)
+    np.savez_compressed(os.path.join(out_dir, "infer_1img.npz"), H=H, W=W, label=lab.numpy(),
+                        norm_cam=ns["norm_cam"].astype(np.float32), pred=ns["pred"].astype(np.uint8))
+    print("wrote infer_1img", ns["norm_cam"].shape, np.bincount(ns["pred"].reshape(-1)))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    os.makedirs(a.out, exist_ok=True)
+    torch.manual_seed(0)
+    R, visualization, torchutils = load_reference()
+    sd = synth.procedural_state_dict(0)
+    todo = a.only.split(",") if a.only else ["fwd", "step", "sgd", "topk", "infer"]
+    if "fwd" in todo:
+        fwd_golden(R, a.out, "net_fwd_eval_104x72", 1, (104, 72), 11, sd)
+        fwd_golden(R, a.out, "net_fwd_eval_128", 2, 128, 12, sd)
+    if "step" in todo:
+        step_golden(R, visualization, a.out, "step_S160_N2", 2, 160, 21, sd, py_seed=7)
+        step_golden(R, visualization, a.out, "step_S128_N3", 3, 128, 22, sd, py_seed=8)
+    if "sgd" in todo:
+        sgd_golden(torchutils, a.out)
+    if "topk" in todo:
+        topk_pattern_golden(a.out)
+    if "infer" in todo:
+        infer_golden(R, a.out, sd)
+
+
+if __name__ == "__main__":
+    main()
