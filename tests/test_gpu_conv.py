@@ -1,0 +1,137 @@
+"""GPU parity: the HIP implicit-GEMM conv (fwd / dgrad / wgrad / stem) through the C ABI against
+torch's CPU convolution on the same seeded inputs (the op the reference's CPU path runs)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(shape, generator=g) * 2 - 1) * scale
+
+
+def _nhwc(x):      # [N,C,H,W] -> contiguous [N,H,W,C]
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+CASES = [
+    # N, H, W, IC, OC, k, stride, dil
+    (2, 20, 20, 64, 128, 3, 1, 1),
+    (1, 23, 17, 128, 64, 3, 1, 2),
+    (2, 14, 14, 64, 256, 3, 1, 4),
+    (2, 21, 19, 64, 128, 3, 2, 1),
+    (2, 20, 20, 128, 128, 1, 1, 1),
+    (1, 21, 19, 64, 192, 1, 2, 1),
+    (1, 9, 9, 256, 24, 1, 1, 1),
+]
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("case", CASES)
+def test_conv_fwd_dgrad_wgrad(case, dt):
+    from wseg_amd import _lib as L
+    N, H, W, IC, OC, k, s, d = case
+    tdt = torch.float32 if dt == "f32" else torch.bfloat16
+    pad = d * (k // 2)
+    OH = (H + 2 * pad - d * (k - 1) - 1) // s + 1
+    OW = (W + 2 * pad - d * (k - 1) - 1) // s + 1
+    x = _rand((N, IC, H, W), 1).to(tdt).float()
+    w = _rand((OC, IC, k, k), 2, (2.0 / (IC * k * k)) ** 0.5).to(tdt).float()
+    dy = _rand((N, OC, OH, OW), 3).to(tdt).float()
+    x.requires_grad_(True)
+    w.requires_grad_(True)
+    y = F.conv2d(x, w, None, s, pad, d)
+    y.backward(dy)
+    tol = dict(rtol=2e-5, atol=2e-5) if dt == "f32" else dict(rtol=2e-2, atol=2e-2)
+
+    dev = "cuda"
+    xg = _nhwc(x.detach()).to(dev, tdt)
+    w_krsc = w.detach().permute(0, 2, 3, 1).contiguous()            # [OC][k][k][IC] f32 master
+    wm = w_krsc.to(dev)
+    wf = torch.empty(OC, k * k, IC, device=dev, dtype=tdt)
+    wt = torch.empty(IC, k * k, OC, device=dev, dtype=tdt)
+    L.pack_weights(wm, wf, wt, OC, k * k, IC, OC, IC, L.dtype_code(wf))
+    # forward
+    yg = torch.empty(N, OH, OW, OC, device=dev, dtype=tdt)
+    L.conv_igemm(xg, wf, yg, N=N, IH=H, IW=W, IC=IC, OH=OH, OW=OW, OC=OC, KH=k, KW=k, stride=s, dil=d, pad=pad)
+    np.testing.assert_allclose(yg.float().cpu().numpy(), _nhwc(y.detach()).numpy(), **tol)
+    # data gradient (needs OC % (128B/es) == 0 as the reduction dim)
+    es = 4 if dt == "f32" else 2
+    dyg = _nhwc(dy).to(dev, tdt)
+    if (OC * es) % 128 == 0:
+        dxg = torch.empty(N, H, W, IC, device=dev, dtype=tdt)
+        L.conv_igemm(dyg, wt, dxg, N=N, IH=OH, IW=OW, IC=OC, OH=H, OW=W, OC=IC, KH=k, KW=k, stride=s, dil=d, pad=pad, mode=1)
+        np.testing.assert_allclose(dxg.float().cpu().numpy(), _nhwc(x.grad).numpy(), **tol)
+    # weight gradient (f32, accumulating)
+    dwg = torch.zeros(OC, k * k, IC, device=dev, dtype=torch.float32)
+    L.conv_wgrad(xg, dyg, dwg, N=N, IH=H, IW=W, IC=IC, OH=OH, OW=OW, OC=OC, KH=k, KW=k, stride=s, dil=d, pad=pad)
+    ref = w.grad.permute(0, 2, 3, 1).reshape(OC, k * k, IC).numpy()
+    scale = np.abs(ref).max()
+    wtol = 2e-5 if dt == "f32" else 1e-2
+    assert np.abs(dwg.cpu().numpy() - ref).max() / scale < wtol
+    # split-K path + accumulation on top of existing content
+    L.conv_wgrad(xg, dyg, dwg, N=N, IH=H, IW=W, IC=IC, OH=OH, OW=OW, OC=OC, KH=k, KW=k, stride=s, dil=d, pad=pad, split_k=3)
+    assert np.abs(dwg.cpu().numpy() - 2 * ref).max() / scale < 2 * wtol
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_conv_epilogues(dt):
+    """fused BN-ReLU-dropout second output (forward) and masked-scale (+residual) epilogue (backward)."""
+    from wseg_amd import _lib as L
+    tdt = torch.float32 if dt == "f32" else torch.bfloat16
+    N, H, W, IC, OC, k = 2, 12, 10, 64, 128, 3
+    dev = "cuda"
+    x = _rand((N, IC, H, W), 1).to(tdt).float()
+    w = _rand((OC, IC, k, k), 2, 0.06).to(tdt).float()
+    res = _rand((N, OC, H, W), 4).to(tdt).float()
+    pre = _rand((N, OC, H, W), 5).to(tdt).float()
+    scale, shift = _rand((OC,), 6) + 1.5, _rand((OC,), 7)
+    drop = (torch.rand(N, OC, generator=torch.Generator().manual_seed(8)) > 0.5).float() * 2
+    y = F.conv2d(x, w, None, 1, 1, 1)
+    raw = y + pre + res
+    act = F.relu(raw * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)) * drop.view(N, OC, 1, 1)
+    xg = _nhwc(x).to(dev, tdt)
+    wf = w.permute(0, 2, 3, 1).reshape(OC, k * k, IC).contiguous().to(dev, tdt)
+    out = torch.empty(N, H, W, OC, device=dev, dtype=tdt)
+    out2 = torch.empty(N, H, W, OC, device=dev, dtype=tdt)
+    L.conv_igemm(xg, wf, out, out2, N=N, IH=H, IW=W, IC=IC, OH=H, OW=W, OC=OC, KH=k, KW=k, pad=1,
+                 r_pre=_nhwc(pre).to(dev, tdt), r_post=_nhwc(res).to(dev, tdt),
+                 scale=scale.to(dev), shift=shift.to(dev), drop=drop.to(dev))
+    tol = dict(rtol=2e-5, atol=2e-5) if dt == "f32" else dict(rtol=2e-2, atol=3e-2)
+    np.testing.assert_allclose(out.float().cpu().numpy(), _nhwc(raw).numpy(), **tol)
+    # out2 is computed from the unrounded sum in-kernel; compare loosely in bf16
+    np.testing.assert_allclose(out2.float().cpu().numpy(), _nhwc(act).numpy(), **tol)
+    # epi 1: (acc + pre) * scale * drop * (mask > 0) + post
+    mask = _rand((N, OC, H, W), 9)
+    exp = (y + pre) * scale.view(1, -1, 1, 1) * drop.view(N, OC, 1, 1) * (mask > 0).float() + res
+    L.conv_igemm(xg, wf, out, N=N, IH=H, IW=W, IC=IC, OH=H, OW=W, OC=OC, KH=k, KW=k, pad=1, epi=1,
+                 r_pre=_nhwc(pre).to(dev, tdt), r_post=_nhwc(res).to(dev, tdt), mask=_nhwc(mask).to(dev, tdt),
+                 scale=scale.to(dev), drop=drop.to(dev))
+    np.testing.assert_allclose(out.float().cpu().numpy(), _nhwc(exp).numpy(), **tol)
+    # epi 2 with an output row stride and channel offset (writes into a wider buffer)
+    wide = torch.zeros(N, H, W, 256, device=dev, dtype=tdt)
+    L.conv_igemm(xg, wf, wide[..., 64:], N=N, IH=H, IW=W, IC=IC, OH=H, OW=W, OC=OC, KH=k, KW=k, pad=1, epi=2, ld_out=256)
+    np.testing.assert_allclose(wide[..., 64:192].float().cpu().numpy(), _nhwc(F.relu(y)).numpy(), **tol)
+    assert float(wide[..., :64].abs().max()) == 0 and float(wide[..., 192:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_stem(dt):
+    from wseg_amd import _lib as L
+    tdt = torch.float32 if dt == "f32" else torch.bfloat16
+    N, H, W = 2, 37, 70
+    x = _rand((N, 3, H, W), 1)
+    w = _rand((64, 3, 3, 3), 2, 0.3)
+    scale, shift = _rand((64,), 3) + 1.5, _rand((64,), 4)
+    y = F.conv2d(x, w, None, 1, 1)
+    act = F.relu(y * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    dev = "cuda"
+    raw_g = torch.empty(N, H, W, 64, device=dev, dtype=tdt)
+    act_g = torch.empty(N, H, W, 64, device=dev, dtype=tdt)
+    L.stem_conv(x.to(dev), w.permute(0, 2, 3, 1).contiguous().to(dev), scale.to(dev), shift.to(dev), raw_g, act_g, N, H, W, L.dtype_code(raw_g))
+    tol = dict(rtol=1e-5, atol=1e-5) if dt == "f32" else dict(rtol=1e-2, atol=2e-2)
+    np.testing.assert_allclose(raw_g.float().cpu().numpy(), _nhwc(y).numpy(), **tol)
+    np.testing.assert_allclose(act_g.float().cpu().numpy(), _nhwc(act).numpy(), **tol)

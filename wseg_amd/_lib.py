@@ -1,0 +1,108 @@
+"""ctypes binding of libwseg_hip.so (the C ABI of include/wseg_hip.h).
+
+There is deliberately NO fallback: if the library is missing the import raises, and every
+wrapper raises RuntimeError(wseg_last_error()) on a non-zero status.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libwseg_hip.so")
+
+F32, BF16 = 0, 1
+TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16}
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("inp", C.c_void_p), ("w", C.c_void_p), ("out", C.c_void_p), ("out2", C.c_void_p),
+                ("r_pre", C.c_void_p), ("r_post", C.c_void_p), ("mask", C.c_void_p),
+                ("scale", C.c_void_p), ("shift", C.c_void_p), ("drop", C.c_void_p),
+                ("N", C.c_int32), ("IH", C.c_int32), ("IW", C.c_int32), ("IC", C.c_int32), ("ld_in", C.c_int32),
+                ("OH", C.c_int32), ("OW", C.c_int32), ("OC", C.c_int32), ("ld_out", C.c_int32), ("ld_out2", C.c_int32),
+                ("ld_rpre", C.c_int32), ("ld_rpost", C.c_int32), ("ld_mask", C.c_int32),
+                ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("dil", C.c_int32), ("pad", C.c_int32),
+                ("mode", C.c_int32), ("epi", C.c_int32), ("dtype", C.c_int32), ("relu_out2", C.c_int32)]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("dy", C.c_void_p), ("dw", C.c_void_p),
+                ("N", C.c_int32), ("IH", C.c_int32), ("IW", C.c_int32), ("IC", C.c_int32), ("ld_x", C.c_int32),
+                ("OH", C.c_int32), ("OW", C.c_int32), ("OC", C.c_int32), ("ld_dy", C.c_int32),
+                ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("dil", C.c_int32), ("pad", C.c_int32),
+                ("dtype", C.c_int32), ("split_k", C.c_int32), ("IC_dw", C.c_int32), ("OC_dw", C.c_int32)]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(wseg_amd has no CPU/eager fallback)")
+    lib = C.CDLL(LIB_PATH)
+    lib.wseg_last_error.restype = C.c_char_p
+    lib.wseg_version.restype = C.c_int
+    return lib
+
+
+lib = _load()
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def check(status, what):
+    if status != 0:
+        raise RuntimeError(f"{what} failed ({status}): {lib.wseg_last_error().decode()}")
+
+
+def dtype_code(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def conv_igemm(inp, w, out=None, out2=None, *, N, IH, IW, IC, OH, OW, OC, KH, KW, stride=1, dil=1, pad=0,
+               mode=0, epi=0, r_pre=None, r_post=None, mask=None, scale=None, shift=None, drop=None,
+               ld_in=None, ld_out=None, ld_out2=None, ld_rpre=None, ld_rpost=None, ld_mask=None, relu_out2=1):
+    d = ConvDesc()
+    d.inp, d.w, d.out, d.out2 = _ptr(inp), _ptr(w), _ptr(out), _ptr(out2)
+    d.r_pre, d.r_post, d.mask = _ptr(r_pre), _ptr(r_post), _ptr(mask)
+    d.scale, d.shift, d.drop = _ptr(scale), _ptr(shift), _ptr(drop)
+    d.N, d.IH, d.IW, d.IC, d.ld_in = N, IH, IW, IC, ld_in or IC
+    d.OH, d.OW, d.OC, d.ld_out, d.ld_out2 = OH, OW, OC, ld_out or OC, ld_out2 or OC
+    d.ld_rpre, d.ld_rpost, d.ld_mask = ld_rpre or OC, ld_rpost or OC, ld_mask or OC
+    d.KH, d.KW, d.stride, d.dil, d.pad = KH, KW, stride, dil, pad
+    d.mode, d.epi, d.dtype, d.relu_out2 = mode, epi, dtype_code(inp), relu_out2
+    check(lib.wseg_conv_igemm(C.byref(d), C.c_void_p(stream_ptr())), "wseg_conv_igemm")
+
+
+def conv_wgrad(x, dy, dw, *, N, IH, IW, IC, OH, OW, OC, KH, KW, stride=1, dil=1, pad=0,
+               ld_x=None, ld_dy=None, split_k=0, IC_dw=None, OC_dw=None):
+    d = WgradDesc()
+    d.x, d.dy, d.dw = _ptr(x), _ptr(dy), _ptr(dw)
+    d.N, d.IH, d.IW, d.IC, d.ld_x = N, IH, IW, IC, ld_x or IC
+    d.OH, d.OW, d.OC, d.ld_dy = OH, OW, OC, ld_dy or OC
+    d.KH, d.KW, d.stride, d.dil, d.pad = KH, KW, stride, dil, pad
+    d.dtype, d.split_k = dtype_code(x), split_k
+    d.IC_dw, d.OC_dw = IC_dw or IC, OC_dw or OC
+    assert dw.dtype == torch.float32
+    check(lib.wseg_conv_wgrad(C.byref(d), C.c_void_p(stream_ptr())), "wseg_conv_wgrad")
+
+
+def pack_weights(master, fwd, tr, OC, T, IC, OCp, ICp, dtype):
+    check(lib.wseg_pack_weights(C.c_void_p(_ptr(master)), C.c_void_p(_ptr(fwd)), C.c_void_p(_ptr(tr)),
+                                OC, T, IC, OCp, ICp, dtype, C.c_void_p(stream_ptr())), "wseg_pack_weights")
+
+
+def stem_conv(x, w, scale, shift, raw, act, N, H, W, dtype):
+    check(lib.wseg_stem_conv(C.c_void_p(_ptr(x)), C.c_void_p(_ptr(w)), C.c_void_p(_ptr(scale)), C.c_void_p(_ptr(shift)),
+                             C.c_void_p(_ptr(raw)), C.c_void_p(_ptr(act)), N, H, W, dtype,
+                             C.c_void_p(stream_ptr())), "wseg_stem_conv")

@@ -1,0 +1,292 @@
+// conv_igemm.hip — NHWC convolution forward / data-gradient as an implicit GEMM on MFMA.
+//
+//   C[m][oc] = sum_{tap} sum_{ic} IN[pix(m,tap)][ic] * W[oc][tap][ic]
+//
+// Both operands are K-contiguous ("pixel rows" of channels, weight rows of [tap][ic]), so both
+// LDS tiles are [128 rows][128 B] and are filled by LDS-DMA (global_load_lds_dwordx4): the
+// im2col gather is nothing but the per-lane SOURCE address; zero padding is a 256-B zero page.
+// Tile 128(M pixels) x 128(N out-channels) x 128 B of K per step, 4 waves (2x2), each wave a
+// 64x64 sub-tile = 4x4 MFMA 16x16 accumulators.  bf16: v_mfma_f32_16x16x32_bf16;
+// f32 (parity mode): v_mfma_f32_16x16x4_f32 (bit-exact f32 fma chain).
+// LDS rows are XOR-swizzled at 16-B granularity (phys = chunk ^ ((row>>1)&7)) — applied on the
+// DMA source side and on the ds_read side (the LDS image itself stays lane-linear).
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, ROWB = 128;      // rows per tile, bytes of K per LDS row
+constexpr int TILE_BYTES = BM * ROWB;              // 16 KiB per operand tile
+constexpr int EPI_LD = BN + 4;                     // f32 epilogue image row stride (floats)
+constexpr int SMEM_BYTES = BM * EPI_LD * 4;        // 67584 B  (>= 2 stages * 2 tiles * 16 KiB)
+static_assert(SMEM_BYTES >= 4 * TILE_BYTES, "epilogue image must cover the staging ring");
+
+struct Args {
+  wseg_conv_desc d;
+  int M;            // N*OH*OW
+  int taps;         // KH*KW
+  int cpt;          // K-steps per tap = IC*ES/128
+  int ntn;          // column tiles
+  int nwg;
+};
+
+template <int DT>
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const Args a) {
+  constexpr int ES = elem<DT>::size;
+  constexpr int CH = 16 / ES;                      // elements per 16-B chunk
+  __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
+  const wseg_conv_desc& d = a.d;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tile = xcd_remap(blockIdx.x, a.nwg);
+  const int tm = tile / a.ntn, tn = tile - tm * a.ntn;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const char* zero = reinterpret_cast<const char*>(g_wseg_zero_page);
+  const char* IN = reinterpret_cast<const char*>(d.in);
+  const char* Wp = reinterpret_cast<const char*>(d.w);
+
+  // ---- staging assignment: thread -> 4 A rows + 4 B rows, one 16-B chunk each per K-step
+  const int srow = lane >> 3;                      // row within an 8-row DMA piece
+  const int pch = lane & 7;                        // physical 16-B chunk in the 128-B row
+  int a_iy0[4], a_ix0[4];
+  long a_img[4];                                   // n*IH*IW, or -1 when the row is beyond M
+  const char* bptr[4];
+  int b_inc[4];
+  int lch[4];                                      // logical chunk this lane fetches for piece i
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = wid * 32 + i * 8 + srow;         // row inside the tile
+    lch[i] = pch ^ ((r >> 1) & 7);
+    const int m = m0 + r;
+    if (m < a.M) {
+      const int hw = d.OH * d.OW;
+      const int n = m / hw, rem = m - n * hw;
+      const int oy = rem / d.OW, ox = rem - oy * d.OW;
+      a_img[i] = (long)n * d.IH * d.IW;
+      if (d.mode == 0) { a_iy0[i] = oy * d.stride - d.pad; a_ix0[i] = ox * d.stride - d.pad; }
+      else             { a_iy0[i] = oy + d.pad;            a_ix0[i] = ox + d.pad; }
+    } else {
+      a_img[i] = -1; a_iy0[i] = 0; a_ix0[i] = 0;
+    }
+    const int oc = n0 + r;
+    if (oc < d.OC) {
+      bptr[i] = Wp + ((size_t)oc * a.taps * d.IC + (size_t)lch[i] * CH) * ES;
+      b_inc[i] = ROWB;
+    } else {
+      bptr[i] = zero + pch * 16; b_inc[i] = 0;
+    }
+  }
+  const char* aptr[4];
+  int a_inc[4];
+  auto set_tap = [&](int tap) {
+    const int ky = tap / d.KW, kx = tap - ky * d.KW;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int iy, ix; bool ok = a_img[i] >= 0;
+      if (d.mode == 0) {
+        iy = a_iy0[i] + ky * d.dil; ix = a_ix0[i] + kx * d.dil;
+      } else {
+        const int ty = a_iy0[i] - ky * d.dil, tx = a_ix0[i] - kx * d.dil;
+        ok = ok && ty >= 0 && tx >= 0;
+        if (d.stride == 1) { iy = ty; ix = tx; }
+        else { iy = ty / d.stride; ix = tx / d.stride; ok = ok && (iy * d.stride == ty) && (ix * d.stride == tx); }
+      }
+      ok = ok && iy >= 0 && iy < d.IH && ix >= 0 && ix < d.IW;
+      if (ok) {
+        aptr[i] = IN + ((size_t)(a_img[i] + (long)iy * d.IW + ix) * d.ld_in + (size_t)lch[i] * CH) * ES;
+        a_inc[i] = ROWB;
+      } else {
+        aptr[i] = zero + pch * 16; a_inc[i] = 0;
+      }
+    }
+  };
+
+  auto stage = [&](int buf) {
+    char* la = smem + buf * 2 * TILE_BYTES + wid * 32 * ROWB;
+    char* lb = la + TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      glds16(aptr[i], la + i * 8 * ROWB);
+      glds16(bptr[i], lb + i * 8 * ROWB);
+      aptr[i] += a_inc[i];
+      bptr[i] += b_inc[i];
+    }
+  };
+
+  // ---- MFMA read addressing
+  const int wr = wid >> 1, wc = wid & 1;
+  const int frow = lane & 15, fk = lane >> 4;
+  const int sw = (lane >> 1) & 7;                  // ((row>>1)&7) for row = ...+16*i+frow
+  const int a_rd = (wr * 64 + frow) * ROWB;
+  const int b_rd = TILE_BYTES + (wc * 64 + frow) * ROWB;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = a.taps * a.cpt;
+  int tap = 0, cc = 0;
+  set_tap(0);
+  stage(0);
+  __syncthreads();                                 // (emits vmcnt(0): DMA landed)
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) {
+      if (++cc == a.cpt) { cc = 0; ++tap; set_tap(tap); }
+      stage(cur ^ 1);
+    }
+    const char* base = smem + cur * 2 * TILE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int off = ((ks * 4 + fk) ^ sw) * 16;
+      if constexpr (DT == WSEG_BF16) {
+        bf16x8 af[4], bf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          af[i] = *reinterpret_cast<const bf16x8*>(base + a_rd + i * 16 * ROWB + off);
+          bf[i] = *reinterpret_cast<const bf16x8*>(base + b_rd + i * 16 * ROWB + off);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+      } else {
+        f32x4 af[4], bf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          af[i] = *reinterpret_cast<const f32x4*>(base + a_rd + i * 16 * ROWB + off);
+          bf[i] = *reinterpret_cast<const f32x4*>(base + b_rd + i * 16 * ROWB + off);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();                               // next stage landed, this stage fully read
+    cur ^= 1;
+  }
+
+  // ---- epilogue: accumulators -> LDS f32 image -> coalesced 8-channel vectors
+  float* img = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = wr * 64 + i * 16 + fk * 4;   // C/D: col = lane&15, row = (lane>>4)*4 + reg
+      const int col = wc * 64 + j * 16 + frow;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) img[(row + e) * EPI_LD + col] = acc[i][j][e];
+    }
+  __syncthreads();
+
+  const int hw = d.OH * d.OW;
+#pragma unroll 1
+  for (int it = 0; it < 8; ++it) {
+    const int idx = it * 256 + tid;
+    const int row = idx >> 4, cv = (idx & 15) * 8;
+    const int m = m0 + row, oc = n0 + cv;
+    if (m >= a.M || oc >= d.OC) continue;          // OC is a multiple of 8 (host-checked)
+    float v[8];
+    {
+      const f32x4 p0 = *reinterpret_cast<const f32x4*>(&img[row * EPI_LD + cv]);
+      const f32x4 p1 = *reinterpret_cast<const f32x4*>(&img[row * EPI_LD + cv + 4]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] = p0[e]; v[4 + e] = p1[e]; }
+    }
+    if (d.r_pre) {
+      float r[8]; load8<DT>(d.r_pre, (size_t)m * d.ld_rpre + oc, r);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += r[e];
+    }
+    const int n = m / hw;
+    if (d.epi == 0) {
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = v[e];
+      if (d.r_post) {
+        float r[8]; load8<DT>(d.r_post, (size_t)m * d.ld_rpost + oc, r);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] += r[e];
+      }
+      if (d.out) store8<DT>(d.out, (size_t)m * d.ld_out + oc, o);
+      if (d.out2) {
+        float t[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float s = o[e];
+          if (d.scale) s = s * d.scale[oc + e] + (d.shift ? d.shift[oc + e] : 0.f);
+          if (d.relu_out2) s = fmaxf(s, 0.f);
+          if (d.drop) s *= d.drop[(size_t)n * d.OC + oc + e];
+          t[e] = s;
+        }
+        store8<DT>(d.out2, (size_t)m * d.ld_out2 + oc, t);
+      }
+    } else if (d.epi == 1) {
+      float o[8], mk[8];
+      if (d.mask) load8<DT>(d.mask, (size_t)m * d.ld_mask + oc, mk);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float s = v[e];
+        if (d.scale) s *= d.scale[oc + e];
+        if (d.drop) s *= d.drop[(size_t)n * d.OC + oc + e];
+        if (d.mask) s = mk[e] > 0.f ? s : 0.f;
+        o[e] = s;
+      }
+      if (d.r_post) {
+        float r[8]; load8<DT>(d.r_post, (size_t)m * d.ld_rpost + oc, r);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] += r[e];
+      }
+      store8<DT>(d.out, (size_t)m * d.ld_out + oc, o);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+      store8<DT>(d.out, (size_t)m * d.ld_out + oc, v);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int wseg_conv_igemm(const wseg_conv_desc* d, void* stream) {
+  WSEG_CHECK(d && d->in && d->w && (d->out || d->out2), "conv_igemm: null pointer");
+  WSEG_CHECK(d->dtype == WSEG_F32 || d->dtype == WSEG_BF16, "conv_igemm: bad dtype %d", d->dtype);
+  const int es = d->dtype == WSEG_BF16 ? 2 : 4;
+  WSEG_CHECK((d->IC * es) % ROWB == 0, "conv_igemm: IC=%d must be a multiple of %d", d->IC, ROWB / es);
+  WSEG_CHECK(d->OC % 8 == 0 && d->ld_in % 8 == 0, "conv_igemm: OC=%d / ld_in=%d must be multiples of 8", d->OC, d->ld_in);
+  WSEG_CHECK(d->N > 0 && d->OH > 0 && d->OW > 0 && d->IH > 0 && d->IW > 0, "conv_igemm: empty shape");
+  WSEG_CHECK(d->stride >= 1 && d->dil >= 1 && d->KH >= 1 && d->KW >= 1, "conv_igemm: bad geometry");
+  WSEG_CHECK(d->mode == 0 || d->mode == 1, "conv_igemm: bad mode");
+  WSEG_CHECK(d->epi >= 0 && d->epi <= 2, "conv_igemm: bad epilogue");
+  WSEG_CHECK(d->ld_in >= d->IC, "conv_igemm: ld_in < IC");
+  if (d->out) WSEG_CHECK(d->ld_out >= d->OC && d->ld_out % 8 == 0, "conv_igemm: bad ld_out");
+  if (d->out2) WSEG_CHECK(d->ld_out2 >= d->OC && d->ld_out2 % 8 == 0 && d->epi == 0, "conv_igemm: bad out2");
+  if (d->r_pre) WSEG_CHECK(d->ld_rpre % 8 == 0, "conv_igemm: bad ld_rpre");
+  if (d->r_post) WSEG_CHECK(d->ld_rpost % 8 == 0, "conv_igemm: bad ld_rpost");
+  if (d->mask) WSEG_CHECK(d->ld_mask % 8 == 0, "conv_igemm: bad ld_mask");
+  const long M = (long)d->N * d->OH * d->OW;
+  WSEG_CHECK(M < (1L << 31) && (long)d->N * d->IH * d->IW * d->ld_in < (1L << 40), "conv_igemm: tensor too large");
+  Args a;
+  a.d = *d;
+  a.M = (int)M;
+  a.taps = d->KH * d->KW;
+  a.cpt = d->IC * es / ROWB;
+  a.ntn = (d->OC + BN - 1) / BN;
+  const long ntm = (M + BM - 1) / BM;
+  a.nwg = (int)(ntm * a.ntn);
+  hipStream_t s = (hipStream_t)stream;
+  if (d->dtype == WSEG_BF16)
+    hipLaunchKernelGGL(conv_igemm_kernel<WSEG_BF16>, dim3(a.nwg), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL(conv_igemm_kernel<WSEG_F32>, dim3(a.nwg), dim3(256), 0, s, a);
+  WSEG_LAUNCH_CHECK();
+  return 0;
+}
