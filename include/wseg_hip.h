@@ -59,6 +59,7 @@ typedef struct wseg_conv_desc {
   int32_t KH, KW, stride, dil, pad;
   int32_t mode, epi, dtype;
   int32_t relu_out2;   /* 1: out2 gets the ReLU (default); 0: affine only */
+  int32_t relu_lt;     /* epi 0: ReLU on `out` channels < relu_lt (fused head: f_proj | cam); 0 = none */
 } wseg_conv_desc;
 int wseg_conv_igemm(const wseg_conv_desc* d, void* stream);
 
@@ -90,6 +91,38 @@ int wseg_pack_weights(const float* master, void* fwd, void* tr, int OC, int T, i
 int wseg_stem_conv(const float* x_nchw, const float* w /*[64][3][3][3] = [oc][ky][kx][ic]*/,
                    const float* scale, const float* shift, void* raw, void* act,
                    int N, int H, int W, int dtype, void* stream);
+
+/* ---- CAM head (network/resnet38_contrast.py:34-59) -------------------------------------------
+ * Fused head GEMM rows are [f_proj(128) | cam logits(21) | zero pad] (ld = 192).
+ * head_split : rows -> planar cam_low [N][21][hw] f32 and cmax[n][c] = max_hw relu(cam)   (:41-43)
+ * cam_gate   : the no_grad normalise / bg = 1-max fg / keep-arg-max gate (:44-48) -> G [N*hw][32],
+ *              G[:,21] = 1 (PCM column-sum channel), G[:,22:] = 0
+ * pcm_xs     : x_s = bilinear(x, (h,w), align_corners=True) (:52) into cols [c_xs, c_xs+3) of the
+ *              feature rows `feat` (row stride ld), zeroing the padding cols [c_xs+3, c_end)
+ * head_grad_rows : assemble d(head rows) from d_f_proj (planar [N][128][hw], ReLU-masked by the stored
+ *              rows) and d_cam_low (planar [N][21][hw]).
+ */
+int wseg_head_split(const void* head, int ld, int c0, float* cam_low, float* cmax, int N, int hw, int dtype, void* stream);
+int wseg_cam_gate(const float* cam_low, const float* cmax, float* G, int N, int hw, void* stream);
+int wseg_pcm_xs(const float* x_nchw, void* feat, int ld, int c_xs, int c_end, int N, int H, int W, int h, int w, int dtype, void* stream);
+int wseg_head_grad_rows(const float* d_fproj, const float* d_cam_low, const void* head, void* d_head, int ld, int N, int hw, int dtype, void* stream);
+int wseg_planar_to_rows(const float* planar, void* rows, int ld, int c0, int C, int N, int hw, int dtype, void* stream);
+
+/* planar bilinear resize of [planes][ih][iw] f32 (F.interpolate(mode='bilinear'), align_corners
+ * 0/1 — resnet38_contrast.py:57-59, contrast_train.py:131-134,145-152,180; contrast_infer.py:62).
+ * bwd is the exact adjoint computed by gather (deterministic). plane_mul (nullable) scales plane p. */
+int wseg_resize_planar_fwd(const float* in, float* out, const float* plane_mul, long planes, int ih, int iw, int oh, int ow, int align, void* stream);
+int wseg_resize_planar_bwd(const float* d_out, float* d_in, const float* plane_mul, long planes, int ih, int iw, int oh, int ow, int align, int accumulate, void* stream);
+
+/* ---- PCM (network/resnet38_contrast.py:63-75), flash-style, exact-f32 MFMA ---------------------
+ * l2norm  : Fh = F/(||F||_2 + 1e-5) over the 192 f9 channels of each pixel row (:70)
+ * forward : cam_rv[n][c][j] = sum_i G[i][c] relu(Fh_i.Fh_j) / (sum_i relu(Fh_i.Fh_j) + 1e-5)  (:71-73)
+ * backward: gradient w.r.t. Fh only (the CAM input is no_grad in the reference, :41-48). */
+int wseg_l2norm_forward(const void* F, int ldf, float* Fh, float* nrm, long rows, int dtype, void* stream);
+int wseg_l2norm_backward(const void* F, int ldf, const float* dFh, const float* nrm, void* dF, int lddf, long rows, int dtype, void* stream);
+int wseg_pcm_forward(const float* Fh, const float* G, float* cam_rv, float* den, int N, int hw, void* stream);
+int wseg_pcm_backward(const float* Fh, const float* G, const float* d_cam_rv, const float* cam_rv, const float* den,
+                      float* DN, float* dFh, int N, int hw, void* stream);
 
 #ifdef __cplusplus
 }

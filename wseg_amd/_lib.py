@@ -23,7 +23,8 @@ class ConvDesc(C.Structure):
                 ("OH", C.c_int32), ("OW", C.c_int32), ("OC", C.c_int32), ("ld_out", C.c_int32), ("ld_out2", C.c_int32),
                 ("ld_rpre", C.c_int32), ("ld_rpost", C.c_int32), ("ld_mask", C.c_int32),
                 ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("dil", C.c_int32), ("pad", C.c_int32),
-                ("mode", C.c_int32), ("epi", C.c_int32), ("dtype", C.c_int32), ("relu_out2", C.c_int32)]
+                ("mode", C.c_int32), ("epi", C.c_int32), ("dtype", C.c_int32), ("relu_out2", C.c_int32),
+                ("relu_lt", C.c_int32)]
 
 
 class WgradDesc(C.Structure):
@@ -71,7 +72,8 @@ def dtype_code(t):
 
 def conv_igemm(inp, w, out=None, out2=None, *, N, IH, IW, IC, OH, OW, OC, KH, KW, stride=1, dil=1, pad=0,
                mode=0, epi=0, r_pre=None, r_post=None, mask=None, scale=None, shift=None, drop=None,
-               ld_in=None, ld_out=None, ld_out2=None, ld_rpre=None, ld_rpost=None, ld_mask=None, relu_out2=1):
+               ld_in=None, ld_out=None, ld_out2=None, ld_rpre=None, ld_rpost=None, ld_mask=None, relu_out2=1,
+               relu_lt=0):
     d = ConvDesc()
     d.inp, d.w, d.out, d.out2 = _ptr(inp), _ptr(w), _ptr(out), _ptr(out2)
     d.r_pre, d.r_post, d.mask = _ptr(r_pre), _ptr(r_post), _ptr(mask)
@@ -80,7 +82,7 @@ def conv_igemm(inp, w, out=None, out2=None, *, N, IH, IW, IC, OH, OW, OC, KH, KW
     d.OH, d.OW, d.OC, d.ld_out, d.ld_out2 = OH, OW, OC, ld_out or OC, ld_out2 or OC
     d.ld_rpre, d.ld_rpost, d.ld_mask = ld_rpre or OC, ld_rpost or OC, ld_mask or OC
     d.KH, d.KW, d.stride, d.dil, d.pad = KH, KW, stride, dil, pad
-    d.mode, d.epi, d.dtype, d.relu_out2 = mode, epi, dtype_code(inp), relu_out2
+    d.mode, d.epi, d.dtype, d.relu_out2, d.relu_lt = mode, epi, dtype_code(inp), relu_out2, relu_lt
     check(lib.wseg_conv_igemm(C.byref(d), C.c_void_p(stream_ptr())), "wseg_conv_igemm")
 
 
@@ -106,3 +108,51 @@ def stem_conv(x, w, scale, shift, raw, act, N, H, W, dtype):
     check(lib.wseg_stem_conv(C.c_void_p(_ptr(x)), C.c_void_p(_ptr(w)), C.c_void_p(_ptr(scale)), C.c_void_p(_ptr(shift)),
                              C.c_void_p(_ptr(raw)), C.c_void_p(_ptr(act)), N, H, W, dtype,
                              C.c_void_p(stream_ptr())), "wseg_stem_conv")
+
+
+def _v(x):
+    return C.c_void_p(_ptr(x))
+
+
+def _s():
+    return C.c_void_p(stream_ptr())
+
+
+def head_split(head, ld, c0, cam_low, cmax, N, hw):
+    check(lib.wseg_head_split(_v(head), ld, c0, _v(cam_low), _v(cmax), N, hw, dtype_code(head), _s()), "wseg_head_split")
+
+
+def cam_gate(cam_low, cmax, G, N, hw):
+    check(lib.wseg_cam_gate(_v(cam_low), _v(cmax), _v(G), N, hw, _s()), "wseg_cam_gate")
+
+
+def pcm_xs(x, feat, ld, c_xs, c_end, N, H, W, h, w):
+    check(lib.wseg_pcm_xs(_v(x), _v(feat), ld, c_xs, c_end, N, H, W, h, w, dtype_code(feat), _s()), "wseg_pcm_xs")
+
+
+def head_grad_rows(d_fproj, d_cam_low, head, d_head, ld, N, hw):
+    check(lib.wseg_head_grad_rows(_v(d_fproj), _v(d_cam_low), _v(head), _v(d_head), ld, N, hw, dtype_code(head), _s()), "wseg_head_grad_rows")
+
+
+def resize_planar_fwd(inp, out, planes, ih, iw, oh, ow, align, plane_mul=None):
+    check(lib.wseg_resize_planar_fwd(_v(inp), _v(out), _v(plane_mul), C.c_long(planes), ih, iw, oh, ow, int(align), _s()), "wseg_resize_planar_fwd")
+
+
+def resize_planar_bwd(d_out, d_in, planes, ih, iw, oh, ow, align, accumulate=False, plane_mul=None):
+    check(lib.wseg_resize_planar_bwd(_v(d_out), _v(d_in), _v(plane_mul), C.c_long(planes), ih, iw, oh, ow, int(align), int(accumulate), _s()), "wseg_resize_planar_bwd")
+
+
+def l2norm_forward(F, ldf, Fh, nrm, rows):
+    check(lib.wseg_l2norm_forward(_v(F), ldf, _v(Fh), _v(nrm), C.c_long(rows), dtype_code(F), _s()), "wseg_l2norm_forward")
+
+
+def l2norm_backward(F, ldf, dFh, nrm, dF, lddf, rows):
+    check(lib.wseg_l2norm_backward(_v(F), ldf, _v(dFh), _v(nrm), _v(dF), lddf, C.c_long(rows), dtype_code(F), _s()), "wseg_l2norm_backward")
+
+
+def pcm_forward(Fh, G, cam_rv, den, N, hw):
+    check(lib.wseg_pcm_forward(_v(Fh), _v(G), _v(cam_rv), _v(den), N, hw, _s()), "wseg_pcm_forward")
+
+
+def pcm_backward(Fh, G, d_cam_rv, cam_rv, den, DN, dFh, N, hw):
+    check(lib.wseg_pcm_backward(_v(Fh), _v(G), _v(d_cam_rv), _v(cam_rv), _v(den), _v(DN), _v(dFh), N, hw, _s()), "wseg_pcm_backward")

@@ -216,6 +216,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const Args a) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] += r[e];
       }
+      if (d.relu_lt > 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) if (oc + e < d.relu_lt) o[e] = fmaxf(o[e], 0.f);
+      }
       if (d.out) store8<DT>(d.out, (size_t)m * d.ld_out + oc, o);
       if (d.out2) {
         float t[8];
