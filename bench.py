@@ -1,0 +1,156 @@
+#!/usr/bin/env python
+"""bench.py — training images/sec of the contrast_train hot path at B=16 x 448 x 448 per GPU.
+
+    python bench.py [--gpus N --steps K --warmup W]          (N>1: launched by torch.distributed.run)
+
+One "step" = one full loop body of contrast_train.py:128-399 on a synthetic batch resident in HBM:
+second view, two ResNet-38d forwards, CAM/PCM head, all SEAM + contrast losses, backward,
+gradient all-reduce (N>1), PolyOptimizer step.  Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0        # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_F32_TFLOPS = 157.3
+
+
+def conv_flops_model():
+    """Algorithmic FLOPs per image of fwd+bwd (SURVEY.md §8d / BASELINE.md §2)."""
+    return 2.4292e12
+
+
+def cpu_baseline(sample_n=1, size=448):
+    """The oracle (CPU restatement, pinned to the reference) timed on this box's host cores."""
+    import random
+    from oracle import loss as oloss
+    from oracle import net as onet
+    from wseg_amd import synth
+    sd = synth.procedural_state_dict(0)
+    keys = onet.trainable_keys(sd)
+    for k in keys:
+        sd[k] = sd[k].clone().requires_grad_(True)
+    img = synth.synthetic_images(sample_n, size, 0)
+    lab = synth.synthetic_labels(sample_n, 0)
+    m1 = synth.synthetic_dropout_masks(sample_n, 0)
+    m2 = synth.synthetic_dropout_masks(sample_n, 1)
+    t0 = time.time()
+    out = oloss.train_step(img, lab, sd, m1, m2, 0.20, random.Random(0))
+    out["loss"].backward()
+    dt = time.time() - t0
+    return {"value": sample_n / dt, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 step (fwd both views + loss + bwd) of the CPU oracle at N={sample_n}, {size}x{size}, fp32, "
+                      f"{dt:.1f} s, nproc={os.cpu_count()}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--size", type=int, default=448)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--loss", default=os.environ.get("WSEG_LOSS", "aten"))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from wseg_amd import _lib as L
+    from wseg_amd import synth
+    from wseg_amd.optim import PolyOptimizer
+    from wseg_amd.resnet38_contrast import Net
+    from wseg_amd.train import Trainer
+
+    model = Net(precision=a.precision)
+    groups = _quiet(model.get_parameter_groups)
+    opt = PolyOptimizer([
+        {'params': groups[0], 'lr': 0.01, 'weight_decay': 5e-4},
+        {'params': groups[1], 'lr': 0.02, 'weight_decay': 0},
+        {'params': groups[2], 'lr': 0.1, 'weight_decay': 5e-4},
+        {'params': groups[3], 'lr': 0.2, 'weight_decay': 0}], lr=0.01, weight_decay=5e-4, max_step=10582 // 16 * 8)
+    model.load_state_dict(synth.procedural_state_dict(0, device=dev))
+    model.cuda(dev)
+    model.train()
+    import random
+    trainer = Trainer(model, opt, 0.20, random.Random(rank), False, a.loss)
+    img = synth.synthetic_images(a.batch, a.size, seed=rank, device=dev)
+    lab = synth.synthetic_labels(a.batch, seed=rank, device=dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        trainer.step(img, lab)
+    L.PROFILE = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        losses = trainer.step(img, lab)
+    barrier()
+    dt = time.perf_counter() - t0
+    prof, L.PROFILE = L.PROFILE, None
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms = dt / a.steps * 1e3
+    value = a.batch * world * a.steps / dt
+
+    if rank == 0:
+        # dominant kernel: the implicit-GEMM conv (fwd + dgrad launches), timed with HIP events on the
+        # launch stream during the timed region
+        tot_ms = sum(s.elapsed_time(e) for (s, e, f) in prof)
+        tot_fl = sum(f for (s, e, f) in prof)
+        n_launch = max(1, len(prof))
+        peak = PEAK_BF16_TFLOPS if a.precision == "bf16" else PEAK_F32_TFLOPS
+        achieved = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+        roof = {"bound": "mfma", "kernel": "conv_igemm_kernel", "achieved": round(achieved, 1), "peak": peak,
+                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+                "launches_per_step": n_launch // a.steps,
+                "avg_launch_ms": round(tot_ms / n_launch, 4), "avg_launch_gflop": round(tot_fl / n_launch / 1e9, 2),
+                "whole_step_frac": round(conv_flops_model() * a.batch / (ms * 1e-3) / 1e12 / peak, 4)}
+        line = {"metric": "training images/sec at B=16x448x448 (contrast_train step)", "value": round(value, 2),
+                "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": a.precision if a.precision == "bf16" else "f32", "data": "synthetic",
+                "config": {"workload": f"ResNet-38 contrast, synthetic VOC {a.size}x{a.size}, B={a.batch}/GPU, "
+                                       f"procedural weights, dropout on, loss={a.loss}",
+                           "global_batch": a.batch * world, "parallelism": f"dp{world}"},
+                "loss": float(losses["loss"]), "roofline": roof}
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def _quiet(fn):
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn()
+
+
+if __name__ == "__main__":
+    main()

@@ -124,6 +124,13 @@ int wseg_pcm_forward(const float* Fh, const float* G, float* cam_rv, float* den,
 int wseg_pcm_backward(const float* Fh, const float* G, const float* d_cam_rv, const float* cam_rv, const float* den,
                       float* DN, float* dFh, int N, int hw, void* stream);
 
+/* ---- fused SGD step (tool/torchutils.py:23-33 -> torch.optim.SGD.step) ------------------------
+ * One pass over the flat buffers: d = g*grad_scale + wd*p; buf = first ? d : momentum*buf + d;
+ * p -= lr*buf.  Segments [begin,end) carry the per-group lr / weight_decay (contrast_train.py:91-96). */
+int wseg_sgd_step(float* params, const float* grads, float* momentum_buf, long numel,
+                  const long* seg_begin, const long* seg_end, const float* seg_lr, const float* seg_wd, int nseg,
+                  float momentum, float grad_scale, int first_step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

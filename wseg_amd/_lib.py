@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libwseg_hip.so")
 
 F32, BF16 = 0, 1
+PROFILE = None        # set to a list by bench.py to collect (start_event, end_event, flops) per conv launch
 TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16}
 
 
@@ -83,7 +84,14 @@ def conv_igemm(inp, w, out=None, out2=None, *, N, IH, IW, IC, OH, OW, OC, KH, KW
     d.ld_rpre, d.ld_rpost, d.ld_mask = ld_rpre or OC, ld_rpost or OC, ld_mask or OC
     d.KH, d.KW, d.stride, d.dil, d.pad = KH, KW, stride, dil, pad
     d.mode, d.epi, d.dtype, d.relu_out2, d.relu_lt = mode, epi, dtype_code(inp), relu_out2, relu_lt
+    if PROFILE is not None:                      # bench.py: HIP events on the launch stream around this launch
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
     check(lib.wseg_conv_igemm(C.byref(d), C.c_void_p(stream_ptr())), "wseg_conv_igemm")
+    if PROFILE is not None:
+        ev1.record()
+        pix = N * (OH * OW if mode == 0 else IH * IW)        # algorithmic: the conv's output pixels
+        PROFILE.append((ev0, ev1, 2.0 * pix * IC * OC * KH * KW))
 
 
 def conv_wgrad(x, dy, dw, *, N, IH, IW, IC, OH, OW, OC, KH, KW, stride=1, dil=1, pad=0,
@@ -156,3 +164,13 @@ def pcm_forward(Fh, G, cam_rv, den, N, hw):
 
 def pcm_backward(Fh, G, d_cam_rv, cam_rv, den, DN, dFh, N, hw):
     check(lib.wseg_pcm_backward(_v(Fh), _v(G), _v(d_cam_rv), _v(cam_rv), _v(den), _v(DN), _v(dFh), N, hw, _s()), "wseg_pcm_backward")
+
+
+def sgd_step(params, grads, buf, segs, momentum, grad_scale, first_step):
+    """segs: list of (begin, end, lr, weight_decay) over the flat buffers."""
+    n = len(segs)
+    LongArr, FloatArr = C.c_long * n, C.c_float * n
+    b = LongArr(*[s[0] for s in segs]); e = LongArr(*[s[1] for s in segs])
+    lr = FloatArr(*[s[2] for s in segs]); wd = FloatArr(*[s[3] for s in segs])
+    check(lib.wseg_sgd_step(_v(params), _v(grads), _v(buf), C.c_long(params.numel()), b, e, lr, wd, n,
+                            C.c_float(momentum), C.c_float(grad_scale), int(first_step), _s()), "wseg_sgd_step")

@@ -32,6 +32,7 @@ class Engine:
         self.pack_key = None
         self.injected_masks = None
         self._order = None
+        self.flat_w_version = 0             # bumped by the fused SGD step (raw kernel writes)
 
     # ------------------------------------------------------------------ parameters
     def conv_param(self, name):
@@ -77,6 +78,7 @@ class Engine:
             view = flat_w[off:off + p.numel()].view(oc, kh, kw, ic).permute(0, 3, 1, 2)
             view.copy_(p.data.to(device))
             p.data = view                                        # logical [OC,IC,KH,KW], physical [OC][KH][KW][IC]
+            p._wseg_flat = (self, off, p.numel())                # lets PolyOptimizer find the flat buffers
             self.offsets[n] = (off, p.numel())
             off += p.numel()
         for n in ["conv1a"] + [c[0] for b in arch.BLOCKS if b[0] in arch.FROZEN_BLOCKS for c in arch.block_convs(b)]:
@@ -113,7 +115,8 @@ class Engine:
 
     def ensure_packs(self, device, dt):
         net = self.net
-        key = (dt, str(device)) + tuple(p._version for p in net.parameters()) + tuple(b._version for b in net.buffers())
+        key = (dt, str(device), self.flat_w_version) + tuple(p._version for p in net.parameters()) \
+            + tuple(b._version for b in net.buffers())
         if self.packs is not None and key == self.pack_key:
             return self.packs
         tdt = L.TORCH_DTYPE[dt]
