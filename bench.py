@@ -60,6 +60,9 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--loss", default=os.environ.get("WSEG_LOSS", "aten"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lr", type=float, default=1e-5,
+                    help="base lr; the reference's 0.01 makes the RANDOM procedural weights diverge within 2 steps "
+                         "(measured, scripts/debug_step.py), so the bench steps with a small lr — same kernels, same work")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -83,10 +86,10 @@ def main():
     model = Net(precision=a.precision)
     groups = _quiet(model.get_parameter_groups)
     opt = PolyOptimizer([
-        {'params': groups[0], 'lr': 0.01, 'weight_decay': 5e-4},
-        {'params': groups[1], 'lr': 0.02, 'weight_decay': 0},
-        {'params': groups[2], 'lr': 0.1, 'weight_decay': 5e-4},
-        {'params': groups[3], 'lr': 0.2, 'weight_decay': 0}], lr=0.01, weight_decay=5e-4, max_step=10582 // 16 * 8)
+        {'params': groups[0], 'lr': a.lr, 'weight_decay': 5e-4},
+        {'params': groups[1], 'lr': 2 * a.lr, 'weight_decay': 0},
+        {'params': groups[2], 'lr': 10 * a.lr, 'weight_decay': 5e-4},
+        {'params': groups[3], 'lr': 20 * a.lr, 'weight_decay': 0}], lr=a.lr, weight_decay=5e-4, max_step=10582 // 16 * 8)
     model.load_state_dict(synth.procedural_state_dict(0, device=dev))
     model.cuda(dev)
     model.train()
@@ -120,8 +123,8 @@ def main():
     if rank == 0:
         # dominant kernel: the implicit-GEMM conv (fwd + dgrad launches), timed with HIP events on the
         # launch stream during the timed region
-        tot_ms = sum(s.elapsed_time(e) for (s, e, f) in prof)
-        tot_fl = sum(f for (s, e, f) in prof)
+        tot_ms = sum(p_[0].elapsed_time(p_[1]) for p_ in prof)
+        tot_fl = sum(p_[2] for p_ in prof)
         n_launch = max(1, len(prof))
         peak = PEAK_BF16_TFLOPS if a.precision == "bf16" else PEAK_F32_TFLOPS
         achieved = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0

@@ -110,9 +110,10 @@ int wseg_planar_to_rows(const float* planar, void* rows, int ld, int c0, int C, 
 
 /* planar bilinear resize of [planes][ih][iw] f32 (F.interpolate(mode='bilinear'), align_corners
  * 0/1 — resnet38_contrast.py:57-59, contrast_train.py:131-134,145-152,180; contrast_infer.py:62).
- * bwd is the exact adjoint computed by gather (deterministic). plane_mul (nullable) scales plane p. */
+ * bwd is the exact adjoint computed by gather (deterministic). plane_mul (nullable) scales plane p;
+ * plane_add (nullable, bwd) is a constant added to every d_out element of plane p (the GAP gradient). */
 int wseg_resize_planar_fwd(const float* in, float* out, const float* plane_mul, long planes, int ih, int iw, int oh, int ow, int align, void* stream);
-int wseg_resize_planar_bwd(const float* d_out, float* d_in, const float* plane_mul, long planes, int ih, int iw, int oh, int ow, int align, int accumulate, void* stream);
+int wseg_resize_planar_bwd(const float* d_out, float* d_in, const float* plane_mul, const float* plane_add, long planes, int ih, int iw, int oh, int ow, int align, int accumulate, void* stream);
 
 /* ---- PCM (network/resnet38_contrast.py:63-75), flash-style, exact-f32 MFMA ---------------------
  * l2norm  : Fh = F/(||F||_2 + 1e-5) over the 192 f9 channels of each pixel row (:70)
@@ -123,6 +124,49 @@ int wseg_l2norm_backward(const void* F, int ldf, const float* dFh, const float* 
 int wseg_pcm_forward(const float* Fh, const float* G, float* cam_rv, float* den, int N, int hw, void* stream);
 int wseg_pcm_backward(const float* Fh, const float* G, const float* d_cam_rv, const float* cam_rv, const float* den,
                       float* DN, float* dFh, int N, int hw, void* stream);
+
+/* ---- loss step, contrast_train.py:138-395 (forward values + hand-written gradients) -----------
+ * All maps planar f32 [N][21][npix]; label20 = float [N][20] multi-hot; loss outputs are device
+ * scalars accumulated with atomicAdd (caller zeroes them).
+ *  plane_stats        per (n,c): {max relu(U), min relu(U), sum U, argmax, argmin, 0}      (:142, visualization.py:62-66)
+ *  cls_loss           mean BCE-with-logits of the GAP logits (:159-160) + its per-pixel gradient as a plane bias
+ *  rvmin_values       q = max_{c>=1} U*L and its arg channel (:19-21)
+ *  select_kth         k-th order statistic per row by 4-pass radix select + strict sums (torch.topk(...)[0].sum(), :22, :170-171)
+ *  rvmin_backward     gradient of adaptive_min_pooling_loss into dU
+ *  norm_resize_*      L * bilinear_{S->OS}(max_norm(U)) and its backward incl. the max/min routes (:145-158)
+ *  er_ecr_prep        ER sum + gradients, bg = 1-max fg, max_onehot, signed ECR differences (:163-169)
+ *  ecr_backward       gradient of the top-K mean (:170-171)
+ *  rows_resize_forward  f_proj rows -> [N*oh*ow][128] f32, bilinear align_corners=True (:179)
+ *  head_grad_fused    d(head rows) = [relu-masked adjoint of rows_resize(dF) | d_cam_low | 0]
+ *  pseudo_label       Q6 normalisation, bg threshold, argmax softmax(.*label) (:186-197)
+ *  proto_candidates / proto_merge   per-class top-K (K = npix/8) over the batch, weighted mean, L2 norm (:199-209);
+ *                     candidates are what ranks all-gather for global-batch prototypes
+ *  nce_sims           L2-normalised features and their similarities to both prototype sets (:245-246, :262, :289)
+ *  intra_weights      hard-pixel sampling: random half + similarity rank band per class (:302-331)
+ *  nce_loss_grad      cross-prototype, cross-pseudo-label and intra-view InfoNCE + gradient w.r.t. the features (:261-334)
+ */
+int wseg_plane_stats(const float* U, float* stats, long planes, int npix, void* stream);
+int wseg_cls_loss(const float* stats, const float* label20, float* loss_out, float* plane_bias, int N, int npix, float coef, void* stream);
+int wseg_rvmin_values(const float* U, const float* label20, float* q, unsigned char* argc, int N, int npix, void* stream);
+size_t wseg_select_workspace_bytes(int rows);
+int wseg_select_kth(const float* vals, int rows, int n, int k, int largest, int use_abs, int relu_vals, float* res, void* workspace, void* stream);
+int wseg_select_finish(const float* res, int rows, int k, int relu_vals, float scale, float* loss_out, void* stream);
+int wseg_rvmin_backward(const float* q, const unsigned char* argc, const float* res, const float* label20, float* dU, int N, int npix, int k, float coef, void* stream);
+int wseg_norm_resize_forward(const float* U, const float* stats, const float* label20, float* out, int N, int S, int OS, void* stream);
+int wseg_norm_resize_backward(const float* G, const float* U, const float* stats, const float* label20, float* dU, int N, int S, int OS, void* stream);
+int wseg_er_ecr_prep(const float* c1, const float* c2, const float* r1, const float* r2, float* Gc1, float* Gc2, float* dlt1, float* dlt2,
+                     float* er_sum, int N, int npix, float er_coef, void* stream);
+int wseg_ecr_backward(const float* dlt, const float* res, float* Gr, int N, int per_row, int k, float coef, void* stream);
+int wseg_rows_resize_forward(const void* head, int ld, float* F, int N, int ih, int iw, int oh, int ow, int dtype, void* stream);
+int wseg_head_grad_fused(const float* dF, const float* d_cam_low, const void* head, void* d_head, int ld, int N, int ih, int iw, int oh, int ow, int dtype, void* stream);
+int wseg_pseudo_label(const float* R, const float* label20, float bg_thr, int* y, float* ncam, int N, int npix, void* stream);
+int wseg_proto_candidates(const float* ncam, const float* F, const int* tie_idx, float* cand_val, float* cand_feat, int* cand_const, int N, int npix, int K, void* stream);
+int wseg_proto_merge(const float* cand_val, const float* cand_feat, const int* cand_const, float* protos, int world, int K, void* stream);
+int wseg_nce_sims(const float* F, const float* p_own, const float* p_oth, float* fn, float* nrm, float* S_own, float* S_oth, int P, void* stream);
+int wseg_intra_weights(const int* y, const float* S_own, const float* rkey, const unsigned char* rand_flag, float* w, int P, void* stream);
+int wseg_nce_loss_grad(const float* fn, const float* nrm, const float* S_own, const float* S_oth, const int* y_own, const int* y_oth,
+                       const float* w_intra, const float* p_own, const float* p_oth, float* dF, float* sums, int P,
+                       float coef_cross, float coef_intra, void* stream);
 
 /* ---- fused SGD step (tool/torchutils.py:23-33 -> torch.optim.SGD.step) ------------------------
  * One pass over the flat buffers: d = g*grad_scale + wd*p; buf = first ? d : momentum*buf + d;

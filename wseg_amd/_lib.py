@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libwseg_hip.so")
 
 F32, BF16 = 0, 1
+PROFILE_WGRAD = None
 PROFILE = None        # set to a list by bench.py to collect (start_event, end_event, flops) per conv launch
 TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16}
 
@@ -91,7 +92,8 @@ def conv_igemm(inp, w, out=None, out2=None, *, N, IH, IW, IC, OH, OW, OC, KH, KW
     if PROFILE is not None:
         ev1.record()
         pix = N * (OH * OW if mode == 0 else IH * IW)        # algorithmic: the conv's output pixels
-        PROFILE.append((ev0, ev1, 2.0 * pix * IC * OC * KH * KW))
+        PROFILE.append((ev0, ev1, 2.0 * pix * IC * OC * KH * KW,
+                        f"{'fwd' if mode == 0 else 'dgrad'} {IC}->{OC} k{KH} s{stride} d{dil} {OH}x{OW}"))
 
 
 def conv_wgrad(x, dy, dw, *, N, IH, IW, IC, OH, OW, OC, KH, KW, stride=1, dil=1, pad=0,
@@ -104,7 +106,13 @@ def conv_wgrad(x, dy, dw, *, N, IH, IW, IC, OH, OW, OC, KH, KW, stride=1, dil=1,
     d.dtype, d.split_k = dtype_code(x), split_k
     d.IC_dw, d.OC_dw = IC_dw or IC, OC_dw or OC
     assert dw.dtype == torch.float32
+    if PROFILE_WGRAD is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
     check(lib.wseg_conv_wgrad(C.byref(d), C.c_void_p(stream_ptr())), "wseg_conv_wgrad")
+    if PROFILE_WGRAD is not None:
+        ev1.record()
+        PROFILE_WGRAD.append((ev0, ev1, 2.0 * N * OH * OW * IC * OC * KH * KW, f"wgrad {IC}->{OC} k{KH} s{stride} d{dil} {OH}x{OW}"))
 
 
 def pack_weights(master, fwd, tr, OC, T, IC, OCp, ICp, dtype):
@@ -146,8 +154,8 @@ def resize_planar_fwd(inp, out, planes, ih, iw, oh, ow, align, plane_mul=None):
     check(lib.wseg_resize_planar_fwd(_v(inp), _v(out), _v(plane_mul), C.c_long(planes), ih, iw, oh, ow, int(align), _s()), "wseg_resize_planar_fwd")
 
 
-def resize_planar_bwd(d_out, d_in, planes, ih, iw, oh, ow, align, accumulate=False, plane_mul=None):
-    check(lib.wseg_resize_planar_bwd(_v(d_out), _v(d_in), _v(plane_mul), C.c_long(planes), ih, iw, oh, ow, int(align), int(accumulate), _s()), "wseg_resize_planar_bwd")
+def resize_planar_bwd(d_out, d_in, planes, ih, iw, oh, ow, align, accumulate=False, plane_mul=None, plane_add=None):
+    check(lib.wseg_resize_planar_bwd(_v(d_out), _v(d_in), _v(plane_mul), _v(plane_add), C.c_long(planes), ih, iw, oh, ow, int(align), int(accumulate), _s()), "wseg_resize_planar_bwd")
 
 
 def l2norm_forward(F, ldf, Fh, nrm, rows):
@@ -174,3 +182,37 @@ def sgd_step(params, grads, buf, segs, momentum, grad_scale, first_step):
     lr = FloatArr(*[s[2] for s in segs]); wd = FloatArr(*[s[3] for s in segs])
     check(lib.wseg_sgd_step(_v(params), _v(grads), _v(buf), C.c_long(params.numel()), b, e, lr, wd, n,
                             C.c_float(momentum), C.c_float(grad_scale), int(first_step), _s()), "wseg_sgd_step")
+
+
+# ---------------------------------------------------------------------------------------------- loss kernels
+lib.wseg_select_workspace_bytes.restype = C.c_size_t
+
+
+def _call(name, *args):
+    check(getattr(lib, name)(*args, _s()), name)
+
+
+def _f(x):
+    return C.c_float(x)
+
+
+def plane_stats(U, stats, planes, npix): _call("wseg_plane_stats", _v(U), _v(stats), C.c_long(planes), npix)
+def cls_loss(stats, label20, loss_out, plane_bias, N, npix, coef): _call("wseg_cls_loss", _v(stats), _v(label20), _v(loss_out), _v(plane_bias), N, npix, _f(coef))
+def rvmin_values(U, label20, q, argc, N, npix): _call("wseg_rvmin_values", _v(U), _v(label20), _v(q), _v(argc), N, npix)
+def select_workspace_bytes(rows): return int(lib.wseg_select_workspace_bytes(rows))
+def select_kth(vals, rows, n, k, largest, use_abs, relu_vals, res, ws): _call("wseg_select_kth", _v(vals), rows, n, k, int(largest), int(use_abs), int(relu_vals), _v(res), _v(ws))
+def select_finish(res, rows, k, relu_vals, scale, loss_out): _call("wseg_select_finish", _v(res), rows, k, int(relu_vals), _f(scale), _v(loss_out))
+def rvmin_backward(q, argc, res, label20, dU, N, npix, k, coef): _call("wseg_rvmin_backward", _v(q), _v(argc), _v(res), _v(label20), _v(dU), N, npix, k, _f(coef))
+def norm_resize_forward(U, stats, label20, out, N, S, OS): _call("wseg_norm_resize_forward", _v(U), _v(stats), _v(label20), _v(out), N, S, OS)
+def norm_resize_backward(G, U, stats, label20, dU, N, S, OS): _call("wseg_norm_resize_backward", _v(G), _v(U), _v(stats), _v(label20), _v(dU), N, S, OS)
+def er_ecr_prep(c1, c2, r1, r2, Gc1, Gc2, dlt1, dlt2, er_sum, N, npix, er_coef): _call("wseg_er_ecr_prep", _v(c1), _v(c2), _v(r1), _v(r2), _v(Gc1), _v(Gc2), _v(dlt1), _v(dlt2), _v(er_sum), N, npix, _f(er_coef))
+def ecr_backward(dlt, res, Gr, N, per_row, k, coef): _call("wseg_ecr_backward", _v(dlt), _v(res), _v(Gr), N, per_row, k, _f(coef))
+def rows_resize_forward(head, ld, F, N, ih, iw, oh, ow): _call("wseg_rows_resize_forward", _v(head), ld, _v(F), N, ih, iw, oh, ow, dtype_code(head))
+def head_grad_fused(dF, d_cam_low, head, d_head, ld, N, ih, iw, oh, ow): _call("wseg_head_grad_fused", _v(dF), _v(d_cam_low), _v(head), _v(d_head), ld, N, ih, iw, oh, ow, dtype_code(head))
+def pseudo_label(R, label20, bg_thr, y, ncam, N, npix): _call("wseg_pseudo_label", _v(R), _v(label20), _f(bg_thr), _v(y), _v(ncam), N, npix)
+def proto_candidates(ncam, F, tie_idx, cand_val, cand_feat, cand_const, N, npix, K): _call("wseg_proto_candidates", _v(ncam), _v(F), _v(tie_idx), _v(cand_val), _v(cand_feat), _v(cand_const), N, npix, K)
+def proto_merge(cand_val, cand_feat, cand_const, protos, world, K): _call("wseg_proto_merge", _v(cand_val), _v(cand_feat), _v(cand_const), _v(protos), world, K)
+def nce_sims(F, p_own, p_oth, fn, nrm, S_own, S_oth, P): _call("wseg_nce_sims", _v(F), _v(p_own), _v(p_oth), _v(fn), _v(nrm), _v(S_own), _v(S_oth), P)
+def intra_weights(y, S_own, rkey, rand_flag, w, P): _call("wseg_intra_weights", _v(y), _v(S_own), _v(rkey), _v(rand_flag), _v(w), P)
+def nce_loss_grad(fn, nrm, S_own, S_oth, y_own, y_oth, w_intra, p_own, p_oth, dF, sums, P, coef_cross, coef_intra):
+    _call("wseg_nce_loss_grad", _v(fn), _v(nrm), _v(S_own), _v(S_oth), _v(y_own), _v(y_oth), _v(w_intra), _v(p_own), _v(p_oth), _v(dF), _v(sums), P, _f(coef_cross), _f(coef_intra))

@@ -29,7 +29,7 @@ struct Args {
   int nwg;
 };
 
-template <int DT>
+template <int DT, int EPI>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const Args a) {
   constexpr int ES = elem<DT>::size;
   constexpr int CH = 16 / ES;                      // elements per 16-B chunk
@@ -187,73 +187,102 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const Args a) {
     }
   __syncthreads();
 
+  // Every thread owns ONE 8-channel column group of 8 rows.  All global operands of a chunk of rows
+  // are loaded before any of them is consumed: one memory round trip per chunk instead of one per row
+  // (the dependent-load chain was the whole cost of short-K layers).  Rows beyond M are clamped to
+  // row 0 for the loads and predicated off at the stores (no divergent control flow).
   const int hw = d.OH * d.OW;
+  const int cv = (tid & 15) * 8;
+  const int oc_raw = n0 + cv;
+  const bool col_ok = oc_raw < d.OC;                        // OC is a multiple of 8 (host-checked)
+  const int oc = col_ok ? oc_raw : 0;
+  const bool has_pre = d.r_pre != nullptr, has_post = d.r_post != nullptr, has_mask = d.mask != nullptr;
+  const bool has_drop = d.drop != nullptr, has_scale = d.scale != nullptr, has_shift = d.shift != nullptr;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { sc[e] = 1.f; sh[e] = 0.f; }
+  if (has_scale) load8<WSEG_F32>(d.scale, oc, sc);
+  if (has_shift) load8<WSEG_F32>(d.shift, oc, sh);
+  constexpr int CHK = 4;
 #pragma unroll 1
-  for (int it = 0; it < 8; ++it) {
-    const int idx = it * 256 + tid;
-    const int row = idx >> 4, cv = (idx & 15) * 8;
-    const int m = m0 + row, oc = n0 + cv;
-    if (m >= a.M || oc >= d.OC) continue;          // OC is a multiple of 8 (host-checked)
-    float v[8];
-    {
-      const f32x4 p0 = *reinterpret_cast<const f32x4*>(&img[row * EPI_LD + cv]);
-      const f32x4 p1 = *reinterpret_cast<const f32x4*>(&img[row * EPI_LD + cv + 4]);
+  for (int c0 = 0; c0 < 8; c0 += CHK) {
+    float rpre[CHK][8], rpost[CHK][8], mk[CHK][8], dr[CHK][8];
+    size_t mrow[CHK];
+    bool ok[CHK];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { v[e] = p0[e]; v[4 + e] = p1[e]; }
+    for (int j = 0; j < CHK; ++j) {
+      const int row = ((c0 + j) * 256 + tid) >> 4;
+      ok[j] = col_ok && (m0 + row) < a.M;
+      mrow[j] = ok[j] ? (size_t)(m0 + row) : 0;
     }
-    if (d.r_pre) {
-      float r[8]; load8<DT>(d.r_pre, (size_t)m * d.ld_rpre + oc, r);
+    if (has_pre) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] += r[e];
+      for (int j = 0; j < CHK; ++j) load8<DT>(d.r_pre, mrow[j] * d.ld_rpre + oc, rpre[j]);
     }
-    const int n = m / hw;
-    if (d.epi == 0) {
-      float o[8];
+    if (has_post) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = v[e];
-      if (d.r_post) {
-        float r[8]; load8<DT>(d.r_post, (size_t)m * d.ld_rpost + oc, r);
+      for (int j = 0; j < CHK; ++j) load8<DT>(d.r_post, mrow[j] * d.ld_rpost + oc, rpost[j]);
+    }
+    if (EPI == 1 && has_mask) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] += r[e];
+      for (int j = 0; j < CHK; ++j) load8<DT>(d.mask, mrow[j] * d.ld_mask + oc, mk[j]);
+    }
+    if (EPI != 2 && has_drop) {
+#pragma unroll
+      for (int j = 0; j < CHK; ++j) load8<WSEG_F32>(d.drop, (mrow[j] / hw) * d.OC + oc, dr[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < CHK; ++j) {
+      const int row = ((c0 + j) * 256 + tid) >> 4;
+      const size_t m = mrow[j];
+      float v[8];
+      {
+        const f32x4 p0 = *reinterpret_cast<const f32x4*>(&img[row * EPI_LD + cv]);
+        const f32x4 p1 = *reinterpret_cast<const f32x4*>(&img[row * EPI_LD + cv + 4]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = p0[e]; v[4 + e] = p1[e]; }
       }
-      if (d.relu_lt > 0) {
+      if (has_pre) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) if (oc + e < d.relu_lt) o[e] = fmaxf(o[e], 0.f);
+        for (int e = 0; e < 8; ++e) v[e] += rpre[j][e];
       }
-      if (d.out) store8<DT>(d.out, (size_t)m * d.ld_out + oc, o);
-      if (d.out2) {
-        float t[8];
+      if constexpr (EPI == 0) {
+        if (has_post) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += rpost[j][e];
+        }
+        if (d.relu_lt > 0) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) if (oc + e < d.relu_lt) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (d.out != nullptr && ok[j]) store8<DT>(d.out, m * d.ld_out + oc, v);
+        if (d.out2 != nullptr) {
+          float t[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float x = v[e] * sc[e] + sh[e];
+            if (d.relu_out2) x = fmaxf(x, 0.f);
+            if (has_drop) x *= dr[j][e];
+            t[e] = x;
+          }
+          if (ok[j]) store8<DT>(d.out2, m * d.ld_out2 + oc, t);
+        }
+      } else if constexpr (EPI == 1) {
+        float o[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          float s = o[e];
-          if (d.scale) s = s * d.scale[oc + e] + (d.shift ? d.shift[oc + e] : 0.f);
-          if (d.relu_out2) s = fmaxf(s, 0.f);
-          if (d.drop) s *= d.drop[(size_t)n * d.OC + oc + e];
-          t[e] = s;
+          float x = v[e] * sc[e];
+          if (has_drop) x *= dr[j][e];
+          if (has_mask) x = mk[j][e] > 0.f ? x : 0.f;
+          if (has_post) x += rpost[j][e];
+          o[e] = x;
         }
-        store8<DT>(d.out2, (size_t)m * d.ld_out2 + oc, t);
-      }
-    } else if (d.epi == 1) {
-      float o[8], mk[8];
-      if (d.mask) load8<DT>(d.mask, (size_t)m * d.ld_mask + oc, mk);
+        if (ok[j]) store8<DT>(d.out, m * d.ld_out + oc, o);
+      } else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float s = v[e];
-        if (d.scale) s *= d.scale[oc + e];
-        if (d.drop) s *= d.drop[(size_t)n * d.OC + oc + e];
-        if (d.mask) s = mk[e] > 0.f ? s : 0.f;
-        o[e] = s;
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        if (ok[j]) store8<DT>(d.out, m * d.ld_out + oc, v);
       }
-      if (d.r_post) {
-        float r[8]; load8<DT>(d.r_post, (size_t)m * d.ld_rpost + oc, r);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] += r[e];
-      }
-      store8<DT>(d.out, (size_t)m * d.ld_out + oc, o);
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-      store8<DT>(d.out, (size_t)m * d.ld_out + oc, v);
     }
   }
 }
@@ -287,10 +316,14 @@ extern "C" int wseg_conv_igemm(const wseg_conv_desc* d, void* stream) {
   const long ntm = (M + BM - 1) / BM;
   a.nwg = (int)(ntm * a.ntn);
   hipStream_t s = (hipStream_t)stream;
-  if (d->dtype == WSEG_BF16)
-    hipLaunchKernelGGL(conv_igemm_kernel<WSEG_BF16>, dim3(a.nwg), dim3(256), 0, s, a);
-  else
-    hipLaunchKernelGGL(conv_igemm_kernel<WSEG_F32>, dim3(a.nwg), dim3(256), 0, s, a);
+  WSEG_CHECK(d->out || d->epi == 0, "conv_igemm: epilogue %d needs `out`", d->epi);
+#define WSEG_LAUNCH_CONV(DT_, EPI_) hipLaunchKernelGGL((conv_igemm_kernel<DT_, EPI_>), dim3(a.nwg), dim3(256), 0, s, a)
+  if (d->dtype == WSEG_BF16) {
+    if (d->epi == 0) WSEG_LAUNCH_CONV(WSEG_BF16, 0); else if (d->epi == 1) WSEG_LAUNCH_CONV(WSEG_BF16, 1); else WSEG_LAUNCH_CONV(WSEG_BF16, 2);
+  } else {
+    if (d->epi == 0) WSEG_LAUNCH_CONV(WSEG_F32, 0); else if (d->epi == 1) WSEG_LAUNCH_CONV(WSEG_F32, 1); else WSEG_LAUNCH_CONV(WSEG_F32, 2);
+  }
+#undef WSEG_LAUNCH_CONV
   WSEG_LAUNCH_CHECK();
   return 0;
 }

@@ -107,7 +107,7 @@ __global__ void resize_planar_fwd_kernel(const float* __restrict__ in, float* __
 
 // exact adjoint by GATHER (deterministic, no atomics): d_in[y][x] = sum over outputs that touch it
 __global__ void resize_planar_bwd_kernel(const float* __restrict__ d_out, float* __restrict__ d_in, const float* __restrict__ plane_mul,
-                                         int ih, int iw, int oh, int ow, int align, int accumulate, long total) {
+                                         const float* __restrict__ plane_add, int ih, int iw, int oh, int ow, int align, int accumulate, long total) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
   const int x = (int)(idx % iw); const long r = idx / iw;
@@ -118,6 +118,7 @@ __global__ void resize_planar_bwd_kernel(const float* __restrict__ d_out, float*
   if (sy > 0.f) { oy_lo = max(0, (int)floorf((y - 1) / sy) - 1); oy_hi = min(oh - 1, (int)ceilf((y + 1) / sy) + 1); } else { oy_lo = 0; oy_hi = oh - 1; }
   if (sx > 0.f) { ox_lo = max(0, (int)floorf((x - 1) / sx) - 1); ox_hi = min(ow - 1, (int)ceilf((x + 1) / sx) + 1); } else { ox_lo = 0; ox_hi = ow - 1; }
   const float* g = d_out + (size_t)pl * oh * ow;
+  const float gadd = plane_add ? plane_add[pl] : 0.f;      // a constant added to every d_out element of the plane
   float acc = 0.f;
   for (int oy = oy_lo; oy <= oy_hi; ++oy) {
     int y0, y1; float fy;
@@ -129,7 +130,7 @@ __global__ void resize_planar_bwd_kernel(const float* __restrict__ d_out, float*
       int x0, x1; float fx;
       src_index(ox, sx, align, iw, x0, x1, fx);
       const float wx = (x == x0 ? 1.f - fx : 0.f) + (x == x1 ? fx : 0.f);
-      if (wx != 0.f) row += wx * g[(size_t)oy * ow + ox];
+      if (wx != 0.f) row += wx * (g[(size_t)oy * ow + ox] + gadd);
     }
     acc += wy * row;
   }
@@ -211,10 +212,10 @@ extern "C" int wseg_resize_planar_fwd(const float* in, float* out, const float* 
   return 0;
 }
 
-extern "C" int wseg_resize_planar_bwd(const float* d_out, float* d_in, const float* plane_mul, long planes, int ih, int iw, int oh, int ow, int align, int accumulate, void* stream) {
+extern "C" int wseg_resize_planar_bwd(const float* d_out, float* d_in, const float* plane_mul, const float* plane_add, long planes, int ih, int iw, int oh, int ow, int align, int accumulate, void* stream) {
   WSEG_CHECK(d_out && d_in && planes > 0 && ih > 0 && iw > 0 && oh > 0 && ow > 0, "resize_planar_bwd: bad arguments");
   const long total = planes * ih * iw;
-  hipLaunchKernelGGL(resize_planar_bwd_kernel, GRID1(total), 0, (hipStream_t)stream, d_out, d_in, plane_mul, ih, iw, oh, ow, align, accumulate, total);
+  hipLaunchKernelGGL(resize_planar_bwd_kernel, GRID1(total), 0, (hipStream_t)stream, d_out, d_in, plane_mul, plane_add, ih, iw, oh, ow, align, accumulate, total);
   WSEG_LAUNCH_CHECK();
   return 0;
 }

@@ -1,0 +1,803 @@
+// loss.hip — the SEAM + pixel-to-prototype contrast losses of contrast_train.py:138-395 as HIP
+// kernels (forward values and hand-written gradients).  All 21-class maps are planar f32.
+// The kernels are HBM/latency-bound integer+float work: coalesced planar access, wavefront
+// shuffles for per-pixel 21-wide reductions / ranks, LDS for per-plane and per-class reductions.
+#include <algorithm>
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ void src_index(int o, float scale, int in_size, int& i0, int& i1, float& f) {
+  const float s = scale * o;                       // align_corners=True
+  i0 = (int)s;
+  if (i0 > in_size - 1) i0 = in_size - 1;
+  i1 = i0 + ((i0 < in_size - 1) ? 1 : 0);
+  f = s - i0;
+}
+__device__ __forceinline__ float ac_scale(int in_size, int out_size) {
+  return out_size > 1 ? (float)(in_size - 1) / (out_size - 1) : 0.f;
+}
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < nw; ++i) t += red[i];
+  return t;
+}
+
+// ---- per-plane statistics of U [planes][npix]: max/min of relu(U) with their first index, sum of U
+//      stats[pl] = {mx, mn, sum, (float)argmax, (float)argmin, 0}
+__global__ __launch_bounds__(256) void plane_stats_kernel(const float* __restrict__ U, float* __restrict__ stats, int npix) {
+  __shared__ float s_mx[256], s_mn[256], s_sum[256];
+  __shared__ int s_imx[256], s_imn[256];
+  const int pl = blockIdx.x, tid = threadIdx.x;
+  const float* p = U + (size_t)pl * npix;
+  float mx = -1.f, mn = INFINITY, sum = 0.f;
+  int imx = 0, imn = 0;
+  for (int i = tid; i < npix; i += 256) {
+    const float u = p[i];
+    const float r = fmaxf(u, 0.f);
+    sum += u;
+    if (r > mx) { mx = r; imx = i; }
+    if (r < mn) { mn = r; imn = i; }
+  }
+  s_mx[tid] = mx; s_mn[tid] = mn; s_sum[tid] = sum; s_imx[tid] = imx; s_imn[tid] = imn;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) {
+      if (s_mx[tid + o] > s_mx[tid] || (s_mx[tid + o] == s_mx[tid] && s_imx[tid + o] < s_imx[tid])) { s_mx[tid] = s_mx[tid + o]; s_imx[tid] = s_imx[tid + o]; }
+      if (s_mn[tid + o] < s_mn[tid] || (s_mn[tid + o] == s_mn[tid] && s_imn[tid + o] < s_imn[tid])) { s_mn[tid] = s_mn[tid + o]; s_imn[tid] = s_imn[tid + o]; }
+      s_sum[tid] += s_sum[tid + o];
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    float* o = stats + (size_t)pl * 6;
+    o[0] = s_mx[0]; o[1] = s_mn[0]; o[2] = s_sum[0]; o[3] = __int_as_float(s_imx[0]); o[4] = __int_as_float(s_imn[0]); o[5] = 0.f;
+  }
+}
+
+// ---- classification loss (contrast_train.py:142,155,159-160): z = GAP, mean BCE-with-logits over N*20
+//      out[0] += loss ; dz[n][c] = coef * (sigmoid(z) - y) / (20 N)   (c >= 1; dz[n][0] = 0), as a per-pixel bias /npix
+__global__ void cls_loss_kernel(const float* __restrict__ stats, const float* __restrict__ label20, float* __restrict__ loss_out,
+                                float* __restrict__ plane_bias, int N, int npix, float coef) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < N * 21; i += blockDim.x) {
+    const int n = i / 21, c = i - n * 21;
+    float bias = 0.f;
+    if (c >= 1) {
+      const float z = stats[(size_t)i * 6 + 2] / npix;
+      const float y = label20[n * 20 + c - 1];
+      // -(y*logsigmoid(z) + (1-y)*logsigmoid(-z)); logsigmoid(z) = min(z,0) - log1p(exp(-|z|))
+      const float l1p = log1pf(expf(-fabsf(z)));
+      const float ls_p = fminf(z, 0.f) - l1p, ls_n = fminf(-z, 0.f) - l1p;
+      acc += -(y * ls_p + (1.f - y) * ls_n);
+      const float sg = 1.f / (1.f + expf(-z));
+      bias = coef * (sg - y) / (20.f * N) / npix;           // d loss / d U[n,c,pixel]
+    }
+    plane_bias[i] = bias;
+  }
+  const float tot = block_sum(acc, red);
+  if (threadIdx.x == 0) atomicAdd(loss_out, tot / (20.f * N));
+}
+
+// ---- adaptive min-pooling values (contrast_train.py:16-22): q = max_{c>=1} U[n,c,p]*L[n,c], arg channel
+__global__ void rvmin_values_kernel(const float* __restrict__ U, const float* __restrict__ label20, float* __restrict__ q,
+                                    unsigned char* __restrict__ argc, int npix, long total) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const long n = idx / npix; const int p = (int)(idx - n * npix);
+  float best = -INFINITY; int bc = 1;
+  for (int c = 1; c < 21; ++c) {
+    const float v = U[((size_t)n * 21 + c) * npix + p] * label20[n * 20 + c - 1];
+    if (v > best) { best = v; bc = c; }
+  }
+  q[idx] = best; argc[idx] = (unsigned char)bc;
+}
+
+// ---- radix select of the k-th order statistic per row (values as order-preserving uint keys)
+__device__ __forceinline__ unsigned f2key(float f) { unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float key2f(unsigned k) { unsigned u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k; return __uint_as_float(u); }
+
+// state[row] = {prefix, mask, k_remaining}; one pass handles 8 bits (shift = 24,16,8,0)
+__global__ __launch_bounds__(256) void select_hist_kernel(const float* __restrict__ vals, int n, int use_abs, const unsigned* __restrict__ state,
+                                                          unsigned* __restrict__ hist, int shift) {
+  __shared__ unsigned h[256];
+  const int row = blockIdx.y;
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const unsigned prefix = state[row * 4 + 0], mask = state[row * 4 + 1];
+  const float* v = vals + (size_t)row * n;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    float f = v[i]; if (use_abs) f = fabsf(f);
+    const unsigned k = f2key(f);
+    if ((k & mask) == prefix) atomicAdd(&h[(k >> shift) & 255u], 1u);
+  }
+  __syncthreads();
+  if (h[threadIdx.x]) atomicAdd(&hist[row * 256 + threadIdx.x], h[threadIdx.x]);
+}
+// choose the bucket holding the k-th (k counted from the small end: 1-based rank) and narrow the prefix
+__global__ void select_scan_kernel(unsigned* __restrict__ state, unsigned* __restrict__ hist, int shift, int rows) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= rows) return;
+  unsigned k = state[row * 4 + 2];
+  unsigned cum = 0; int b = 0;
+  for (b = 0; b < 256; ++b) {
+    const unsigned c = hist[row * 256 + b];
+    if (cum + c >= k) break;
+    cum += c;
+  }
+  if (b > 255) b = 255;
+  state[row * 4 + 0] |= ((unsigned)b << shift);
+  state[row * 4 + 1] |= (255u << shift);
+  state[row * 4 + 2] = k - cum;
+  for (int i = 0; i < 256; ++i) hist[row * 256 + i] = 0;
+}
+__global__ void select_init_kernel(unsigned* __restrict__ state, unsigned* __restrict__ hist, int rows, unsigned rank_small) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < rows) { state[i * 4 + 0] = 0; state[i * 4 + 1] = 0; state[i * 4 + 2] = rank_small; state[i * 4 + 3] = 0; }
+  if (i < rows * 256) hist[i] = 0;
+}
+// after 4 passes state.prefix is the key of the threshold.  Accumulate per row:
+//   res[row] = {thr, sum of relu?(v) strictly beyond thr, count strictly beyond, count equal}
+__global__ __launch_bounds__(256) void select_sum_kernel(const float* __restrict__ vals, int n, int use_abs, int largest, int relu_vals,
+                                                         const unsigned* __restrict__ state, float* __restrict__ res) {
+  __shared__ float red[4];
+  const int row = blockIdx.y;
+  const float thr = key2f(state[row * 4 + 0]);
+  const float* v = vals + (size_t)row * n;
+  float s = 0.f, cs = 0.f, ce = 0.f;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    float f = v[i]; if (use_abs) f = fabsf(f);
+    const bool beyond = largest ? (f > thr) : (f < thr);
+    if (beyond) { s += relu_vals ? fmaxf(f, 0.f) : f; cs += 1.f; }
+    else if (f == thr) ce += 1.f;
+  }
+  const float S = block_sum(s, red), CS = block_sum(cs, red), CE = block_sum(ce, red);
+  if (threadIdx.x == 0) {
+    if (blockIdx.x == 0) res[row * 4 + 0] = thr;
+    atomicAdd(&res[row * 4 + 1], S); atomicAdd(&res[row * 4 + 2], CS); atomicAdd(&res[row * 4 + 3], CE);
+  }
+}
+// loss += scale * sum_rows ( sum_strict + (k - cnt_strict) * f(thr) )
+__global__ void select_finish_kernel(const float* __restrict__ res, int rows, int k, int relu_vals, float scale, float* __restrict__ loss_out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float t = 0.f;
+    for (int r = 0; r < rows; ++r) {
+      const float thr = relu_vals ? fmaxf(res[r * 4 + 0], 0.f) : res[r * 4 + 0];
+      t += res[r * 4 + 1] + ((float)k - res[r * 4 + 2]) * thr;
+    }
+    atomicAdd(loss_out, t * scale);
+  }
+}
+
+// ---- rvmin backward: pixels among the k smallest with q > 0 send coef*L to their arg channel
+__global__ void rvmin_bwd_kernel(const float* __restrict__ q, const unsigned char* __restrict__ argc, const float* __restrict__ res,
+                                 const float* __restrict__ label20, float* __restrict__ dU, int npix, int k, float coef, long total) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const long n = idx / npix; const int p = (int)(idx - n * npix);
+  const float v = q[idx], thr = res[n * 4 + 0];
+  float w = 0.f;
+  if (v < thr) w = 1.f;
+  else if (v == thr) { const float ce = res[n * 4 + 3]; w = ce > 0.f ? ((float)k - res[n * 4 + 2]) / ce : 0.f; }
+  if (w > 0.f && v > 0.f) {
+    const int c = argc[idx];
+    dU[((size_t)n * 21 + c) * npix + p] += w * coef * label20[n * 20 + c - 1];
+  }
+}
+
+// ---- out[n,c,P] = L * resize_{S->OS}( relu(relu(U) - mn - e) / (mx - mn + e) )      (visualization.py:62-67 + :145-158)
+__global__ void norm_resize_fwd_kernel(const float* __restrict__ U, const float* __restrict__ stats, const float* __restrict__ label20,
+                                       float* __restrict__ out, int S, int OS, long total) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int ox = (int)(idx % OS); const long r = idx / OS;
+  const int oy = (int)(r % OS); const long pl = r / OS;
+  const int c = (int)(pl % 21); const long n = pl / 21;
+  const float L = c == 0 ? 1.f : label20[n * 20 + c - 1];
+  float v = 0.f;
+  if (L != 0.f) {
+    const float mx = stats[pl * 6 + 0], mn = stats[pl * 6 + 1];
+    const float invD = 1.f / (mx - mn + 1e-5f);
+    int y0, y1, x0, x1; float fy, fx;
+    const float sc = ac_scale(S, OS);
+    src_index(oy, sc, S, y0, y1, fy); src_index(ox, sc, S, x0, x1, fx);
+    const float* p = U + (size_t)pl * S * S;
+    auto f = [&](int y, int x) { return fmaxf(fmaxf(p[(size_t)y * S + x], 0.f) - mn - 1e-5f, 0.f) * invD; };
+    v = (1.f - fy) * ((1.f - fx) * f(y0, x0) + fx * f(y0, x1)) + fy * ((1.f - fx) * f(y1, x0) + fx * f(y1, x1));
+    v *= L;
+  }
+  out[idx] = v;
+}
+
+// backward of the above; one workgroup per plane: scatters into dU and routes the max/min gradients
+__global__ __launch_bounds__(256) void norm_resize_bwd_kernel(const float* __restrict__ G, const float* __restrict__ U, const float* __restrict__ stats,
+                                                              const float* __restrict__ label20, float* __restrict__ dU, int S, int OS) {
+  __shared__ float red[4];
+  const int pl = blockIdx.x;
+  const int c = pl % 21; const int n = pl / 21;
+  const float L = c == 0 ? 1.f : label20[n * 20 + c - 1];
+  if (L == 0.f) return;
+  const float mx = stats[(size_t)pl * 6 + 0], mn = stats[(size_t)pl * 6 + 1];
+  const float invD = 1.f / (mx - mn + 1e-5f);
+  const float sc = ac_scale(S, OS);
+  const float* p = U + (size_t)pl * S * S;
+  float* dp = dU + (size_t)pl * S * S;
+  const float* g = G + (size_t)pl * OS * OS;
+  float A = 0.f, B = 0.f;
+  for (int o = threadIdx.x; o < OS * OS; o += 256) {
+    const float go = g[o] * L;
+    if (go == 0.f) continue;
+    const int oy = o / OS, ox = o - oy * OS;
+    int y0, y1, x0, x1; float fy, fx;
+    src_index(oy, sc, S, y0, y1, fy); src_index(ox, sc, S, x0, x1, fx);
+    const int ys[2] = {y0, y1}, xs[2] = {x0, x1};
+    const float wy[2] = {1.f - fy, fy}, wx[2] = {1.f - fx, fx};
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const float w = wy[a] * wx[b];
+        if (w == 0.f) continue;
+        const size_t qi = (size_t)ys[a] * S + xs[b];
+        const float u = p[qi];
+        const float av = fmaxf(fmaxf(u, 0.f) - mn - 1e-5f, 0.f);
+        if (av > 0.f) {                                   // implies u > 0
+          const float t = go * w * invD;
+          atomicAdd(&dp[qi], t);
+          B += t;
+          A += t * av * invD;
+        }
+      }
+  }
+  const float At = block_sum(A, red), Bt = block_sum(B, red);
+  if (threadIdx.x == 0) {
+    const int imx = __float_as_int(stats[(size_t)pl * 6 + 3]), imn = __float_as_int(stats[(size_t)pl * 6 + 4]);
+    if (p[imx] > 0.f) atomicAdd(&dp[imx], -At);          // d/d mx
+    if (p[imn] > 0.f) atomicAdd(&dp[imn], At - Bt);      // d/d mn
+  }
+}
+
+// ---- ER + ECR preparation on the 128x128 maps (contrast_train.py:163-169)
+// per pixel: ER sum, G_c1/G_c2 (ER gradients, fg only), dlt1 = r1 - oh(c2), dlt2 = r2 - oh(c1) (all 21 channels)
+__global__ void er_ecr_prep_kernel(const float* __restrict__ c1, const float* __restrict__ c2, const float* __restrict__ r1,
+                                   const float* __restrict__ r2, float* __restrict__ Gc1, float* __restrict__ Gc2,
+                                   float* __restrict__ dlt1, float* __restrict__ dlt2, float* __restrict__ er_out,
+                                   int npix, float er_coef, long total) {
+  __shared__ float red[4];
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  float er = 0.f;
+  if (idx < total) {
+    const long n = idx / npix; const int p = (int)(idx - n * npix);
+    const size_t base = (size_t)n * 21 * npix + p;
+    float a[21], b[21];
+    float m1 = -INFINITY, m2 = -INFINITY;
+    for (int c = 1; c < 21; ++c) {
+      a[c] = c1[base + (size_t)c * npix]; b[c] = c2[base + (size_t)c * npix];
+      m1 = fmaxf(m1, a[c]); m2 = fmaxf(m2, b[c]);
+      const float df = a[c] - b[c];
+      er += fabsf(df);
+      const float sg = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
+      Gc1[base + (size_t)c * npix] = sg * er_coef;
+      Gc2[base + (size_t)c * npix] = -sg * er_coef;
+    }
+    Gc1[base] = 0.f; Gc2[base] = 0.f;
+    a[0] = 1.f - m1; b[0] = 1.f - m2;                    // cam[:,0] = 1 - max fg
+    for (int c = 0; c < 21; ++c) {
+      const float oh2 = (c == 0 || b[c] == m2) ? b[c] : 0.f;
+      const float oh1 = (c == 0 || a[c] == m1) ? a[c] : 0.f;
+      dlt1[base + (size_t)c * npix] = r1[base + (size_t)c * npix] - oh2;
+      dlt2[base + (size_t)c * npix] = r2[base + (size_t)c * npix] - oh1;
+    }
+  }
+  const float t = block_sum(er, red);
+  if (threadIdx.x == 0 && t != 0.f) atomicAdd(er_out, t);
+}
+
+// ECR backward: G_r = coef * sign(dlt) for the K largest |dlt| of each sample (ties at thr share the remainder)
+__global__ void ecr_bwd_kernel(const float* __restrict__ dlt, const float* __restrict__ res, float* __restrict__ Gr, int per_row, int k, float coef, long total) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const long row = idx / per_row;
+  const float d = dlt[idx], v = fabsf(d), thr = res[row * 4 + 0];
+  float w = 0.f;
+  if (v > thr) w = 1.f;
+  else if (v == thr) { const float ce = res[row * 4 + 3]; w = ce > 0.f ? ((float)k - res[row * 4 + 2]) / ce : 0.f; }
+  const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+  Gr[idx] = w * sg * coef;
+}
+
+// ---- f_proj rows (head rows cols [0,128), any dtype) -> F [N*oh*ow][128] f32, bilinear align_corners=True
+template <int DT>
+__global__ void rows_resize_fwd_kernel(const void* __restrict__ head, int ld, float* __restrict__ F, int ih, int iw, int oh, int ow, long total) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;      // over N*oh*ow*128
+  if (idx >= total) return;
+  const int ch = (int)(idx & 127); const long pix = idx >> 7;
+  const int ox = (int)(pix % ow); const long r = pix / ow;
+  const int oy = (int)(r % oh); const long n = r / oh;
+  int y0, y1, x0, x1; float fy, fx;
+  src_index(oy, ac_scale(ih, oh), ih, y0, y1, fy); src_index(ox, ac_scale(iw, ow), iw, x0, x1, fx);
+  auto f = [&](int y, int x) { return elem<DT>::ld(head, (((size_t)n * ih + y) * iw + x) * ld + ch); };
+  F[idx] = (1.f - fy) * ((1.f - fx) * f(y0, x0) + fx * f(y0, x1)) + fy * ((1.f - fx) * f(y1, x0) + fx * f(y1, x1));
+}
+
+// ---- d(head rows): cols [0,128) = relu-masked adjoint of the row resize applied to dF, cols [128,149) = d_cam_low, rest 0
+template <int DT>
+__global__ void head_grad_fused_kernel(const float* __restrict__ dF, const float* __restrict__ d_cam, const void* __restrict__ head,
+                                       void* __restrict__ d_head, int ld, int ih, int iw, int oh, int ow, long total) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;      // over N*ih*iw*(ld/8)
+  if (idx >= total) return;
+  const int v8 = ld / 8;
+  const long pix = idx / v8; const int c8 = (int)(idx - pix * v8) * 8;
+  const int x = (int)(pix % iw); const long r = pix / iw;
+  const int y = (int)(r % ih); const long n = r / ih;
+  float o[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = 0.f;
+  if (c8 < 128) {
+    const float sy = ac_scale(ih, oh), sx = ac_scale(iw, ow);
+    int oy_lo, oy_hi, ox_lo, ox_hi;
+    if (sy > 0.f) { oy_lo = max(0, (int)floorf((y - 1) / sy) - 1); oy_hi = min(oh - 1, (int)ceilf((y + 1) / sy) + 1); } else { oy_lo = 0; oy_hi = oh - 1; }
+    if (sx > 0.f) { ox_lo = max(0, (int)floorf((x - 1) / sx) - 1); ox_hi = min(ow - 1, (int)ceilf((x + 1) / sx) + 1); } else { ox_lo = 0; ox_hi = ow - 1; }
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+      int y0, y1; float fy;
+      src_index(oy, sy, ih, y0, y1, fy);
+      const float wy = (y == y0 ? 1.f - fy : 0.f) + (y == y1 ? fy : 0.f);
+      if (wy == 0.f) continue;
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        int x0, x1; float fx;
+        src_index(ox, sx, iw, x0, x1, fx);
+        const float w = wy * ((x == x0 ? 1.f - fx : 0.f) + (x == x1 ? fx : 0.f));
+        if (w == 0.f) continue;
+        const float4* g = reinterpret_cast<const float4*>(dF + ((((size_t)n * oh + oy) * ow + ox) << 7) + c8);
+        const float4 g0 = g[0], g1 = g[1];
+        o[0] += w * g0.x; o[1] += w * g0.y; o[2] += w * g0.z; o[3] += w * g0.w;
+        o[4] += w * g1.x; o[5] += w * g1.y; o[6] += w * g1.z; o[7] += w * g1.w;
+      }
+    }
+    float hv[8];
+    load8<DT>(head, (size_t)pix * ld + c8, hv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) if (!(hv[e] > 0.f)) o[e] = 0.f;
+  } else if (c8 < 152 && d_cam) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = c8 + e - 128;
+      if (c < 21) o[e] = d_cam[(((size_t)n * 21 + c) * ih + y) * iw + x];
+    }
+  }
+  store8<DT>(d_head, (size_t)pix * ld + c8, o);
+}
+
+// ---- pseudo labels (contrast_train.py:186-197): one workgroup per image over npix (=256) pixels
+__global__ __launch_bounds__(256) void pseudo_label_kernel(const float* __restrict__ R, const float* __restrict__ label20, float bg_thr,
+                                                           int* __restrict__ y, float* __restrict__ ncam, int npix) {
+  __shared__ float s_mx[21], s_mn[21];
+  __shared__ float red_a[256], red_b[256];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const float* Rn = R + (size_t)n * 21 * npix;
+  for (int c = 0; c < 21; ++c) {
+    float mx = 0.f, mn = INFINITY;
+    for (int p = tid; p < npix; p += 256) { const float v = fmaxf(Rn[(size_t)c * npix + p], 0.f); mx = fmaxf(mx, v); mn = fminf(mn, v); }
+    red_a[tid] = mx; red_b[tid] = mn;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) { red_a[tid] = fmaxf(red_a[tid], red_a[tid + o]); red_b[tid] = fminf(red_b[tid], red_b[tid + o]); } __syncthreads(); }
+    if (tid == 0) { s_mx[c] = red_a[0]; s_mn[c] = red_b[0]; }
+    __syncthreads();
+  }
+  for (int p = tid; p < npix; p += 256) {
+    float best = -INFINITY; int bc = 0;
+    for (int c = 0; c < 21; ++c) {
+      float v = fmaxf(Rn[(size_t)c * npix + p], 0.f);
+      if (v < s_mn[c] + 1e-5f) v = 0.f;
+      v = (v - s_mn[c] - 1e-5f) / (s_mx[c] - s_mn[c] + 1e-5f);
+      if (c == 0) v = bg_thr;
+      ncam[((size_t)n * 21 + c) * npix + p] = v;
+      const float L = c == 0 ? 1.f : label20[n * 20 + c - 1];
+      const float s = v * L;                               // softmax is monotone: argmax of the logits
+      if (s > best) { best = s; bc = c; }
+    }
+    y[(size_t)n * npix + p] = bc;
+  }
+}
+
+// ---- batch prototypes (contrast_train.py:199-209): one workgroup per class; candidates = top-K of T[c][:]
+//      T[c][p] = ncam[n][c][pix], p = n*npix + pix.  Constant rows use the supplied tie index set (Q5).
+__global__ __launch_bounds__(256) void proto_candidates_kernel(const float* __restrict__ ncam, const float* __restrict__ F, const int* __restrict__ tie_idx,
+                                                               float* __restrict__ cand_val, float* __restrict__ cand_feat, int* __restrict__ cand_const,
+                                                               int N, int npix, int K) {
+  extern __shared__ float sv[];                            // [P] values
+  __shared__ float r_v[256]; __shared__ int r_i[256];
+  __shared__ int sel[64];
+  __shared__ float s_gmin;
+  const int c = blockIdx.x, tid = threadIdx.x;
+  const int P = N * npix;
+  float lmx = -INFINITY, lmn = INFINITY;
+  for (int p = tid; p < P; p += 256) {
+    const int n = p / npix, pix = p - n * npix;
+    const float v = ncam[((size_t)n * 21 + c) * npix + pix];
+    sv[p] = v; lmx = fmaxf(lmx, v); lmn = fminf(lmn, v);
+  }
+  r_v[tid] = lmx; __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (tid < o) r_v[tid] = fmaxf(r_v[tid], r_v[tid + o]); __syncthreads(); }
+  const float gmx = r_v[0]; __syncthreads();
+  r_v[tid] = lmn; __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (tid < o) r_v[tid] = fminf(r_v[tid], r_v[tid + o]); __syncthreads(); }
+  if (tid == 0) s_gmin = r_v[0];
+  __syncthreads();
+  const bool is_const = (gmx == s_gmin);
+  if (is_const) {
+    if (tid < K) sel[tid] = tie_idx[tid];
+    __syncthreads();
+  } else {
+    for (int k = 0; k < K; ++k) {                          // K rounds of (max value, lowest index)
+      float bv = -INFINITY; int bi = 0x7fffffff;
+      for (int p = tid; p < P; p += 256) { const float v = sv[p]; if (v > bv || (v == bv && p < bi)) { bv = v; bi = p; } }
+      r_v[tid] = bv; r_i[tid] = bi; __syncthreads();
+      for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) { if (r_v[tid + o] > r_v[tid] || (r_v[tid + o] == r_v[tid] && r_i[tid + o] < r_i[tid])) { r_v[tid] = r_v[tid + o]; r_i[tid] = r_i[tid + o]; } }
+        __syncthreads();
+      }
+      if (tid == 0) { sel[k] = r_i[0]; sv[r_i[0]] = -INFINITY; }
+      __syncthreads();
+    }
+  }
+  if (tid == 0) cand_const[c] = is_const ? 1 : 0;
+  for (int k = 0; k < K; ++k) {
+    const int p = sel[k];
+    const int n = p / npix, pix = p - n * npix;
+    if (tid == 0) cand_val[c * K + k] = ncam[((size_t)n * 21 + c) * npix + pix];
+    if (tid < 128) cand_feat[((size_t)c * K + k) * 128 + tid] = F[(size_t)p * 128 + tid];
+  }
+}
+// merge world*K candidates per class -> top K -> weighted mean -> L2 normalise (F.normalize eps 1e-12)
+__global__ __launch_bounds__(128) void proto_merge_kernel(const float* __restrict__ cand_val, const float* __restrict__ cand_feat, const int* __restrict__ cand_const,
+                                                          float* __restrict__ protos, int world, int K) {
+  __shared__ float vals[512]; __shared__ int order[64]; __shared__ float red[2];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  const int M = world * K;                                  // gathered layout: [world][21][K]
+  for (int i = tid; i < M; i += 128) { const int w = i / K, k = i - w * K; vals[i] = cand_val[((size_t)w * 21 + c) * K + k]; }
+  __syncthreads();
+  if (tid == 0) {
+    bool cst = true;
+    for (int w = 0; w < world; ++w) cst = cst && cand_const[w * 21 + c];
+    if (cst) { for (int k = 0; k < K; ++k) order[k] = k; }  // fully tied: rank 0's set (global pixels first)
+    else {
+      for (int k = 0; k < K; ++k) {
+        float bv = -INFINITY; int bi = 0;
+        for (int i = 0; i < M; ++i) if (vals[i] > bv) { bv = vals[i]; bi = i; }
+        order[k] = bi; vals[bi] = -INFINITY;
+      }
+    }
+  }
+  __syncthreads();
+  float acc = 0.f, wsum = 0.f;
+  for (int k = 0; k < K; ++k) {
+    const int i = order[k]; const int w = i / K, kk = i - w * K;
+    const float v = cand_val[((size_t)w * 21 + c) * K + kk];
+    acc += v * cand_feat[(((size_t)w * 21 + c) * K + kk) * 128 + tid];
+    wsum += v;
+  }
+  const float pr = acc / wsum;
+  const float ss = block_sum(pr * pr, red);
+  protos[c * 128 + tid] = pr / fmaxf(sqrtf(ss), 1e-12f);
+}
+
+// ---- fn = F/max(||F||,1e-12); S_own = fn.protos_own^T ; S_oth = fn.protos_oth^T    (one wave per pixel)
+__global__ __launch_bounds__(256) void nce_sims_kernel(const float* __restrict__ F, const float* __restrict__ p_own, const float* __restrict__ p_oth,
+                                                       float* __restrict__ fn, float* __restrict__ nrm, float* __restrict__ S_own, float* __restrict__ S_oth, int P) {
+  __shared__ float po[21 * 128], pt[21 * 128];
+  for (int i = threadIdx.x; i < 21 * 128; i += 256) { po[i] = p_own[i]; pt[i] = p_oth[i]; }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  for (int p = blockIdx.x * 4 + (threadIdx.x >> 6); p < P; p += gridDim.x * 4) {
+    const float a = F[(size_t)p * 128 + lane], b = F[(size_t)p * 128 + 64 + lane];
+    float ss = a * a + b * b;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    const float nr = sqrtf(ss);
+    const float inv = 1.f / fmaxf(nr, 1e-12f);
+    const float fa = a * inv, fb = b * inv;
+    fn[(size_t)p * 128 + lane] = fa; fn[(size_t)p * 128 + 64 + lane] = fb;
+    if (lane == 0) nrm[p] = nr;
+    for (int c = 0; c < 21; ++c) {
+      float d1 = fa * po[c * 128 + lane] + fb * po[c * 128 + 64 + lane];
+      float d2 = fa * pt[c * 128 + lane] + fb * pt[c * 128 + 64 + lane];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { d1 += __shfl_xor(d1, o, 64); d2 += __shfl_xor(d2, o, 64); }
+      if (lane == 0) { S_own[(size_t)p * 21 + c] = d1; S_oth[(size_t)p * 21 + c] = d2; }
+    }
+  }
+}
+
+// ---- hard pixel sampling weights (contrast_train.py:302-331), single workgroup, P <= 8192.
+//   key1 = S_own[p][y_p] (similarity order), key2 = random key or host flag.  w[p] = (#selections)/(2*half*C).
+__global__ __launch_bounds__(1024) void intra_weights_kernel(const int* __restrict__ y, const float* __restrict__ S_own, const float* __restrict__ rkey,
+                                                             const unsigned char* __restrict__ rand_flag, float* __restrict__ w, int P) {
+  extern __shared__ unsigned long long keys[];              // [P2] sort buffer
+  __shared__ int cnt[21], start[21], nclass;
+  const int tid = threadIdx.x;
+  int P2 = 1; while (P2 < P) P2 <<= 1;
+  if (tid < 21) cnt[tid] = 0;
+  __syncthreads();
+  for (int p = tid; p < P; p += 1024) atomicAdd(&cnt[y[p]], 1);
+  __syncthreads();
+  if (tid == 0) { int s = 0, C = 0; for (int c = 0; c < 21; ++c) { start[c] = s; s += cnt[c]; if (cnt[c] > 0) ++C; } nclass = C; }
+  for (int p = tid; p < P; p += 1024) w[p] = 0.f;
+  __syncthreads();
+  for (int pass = 0; pass < 2; ++pass) {
+    if (pass == 1 && rand_flag) {                           // host-provided random half (RNG-parity mode)
+      for (int p = tid; p < P; p += 1024) if (rand_flag[p]) { const int c = y[p]; const int half = cnt[c] / 2; if (cnt[c] >= 2) w[p] += 1.f / (2.f * half * nclass); }
+      break;
+    }
+    for (int i = tid; i < P2; i += 1024) {
+      unsigned long long k = ~0ull;
+      if (i < P) {
+        const float f = pass == 0 ? S_own[(size_t)i * 21 + y[i]] : rkey[i];
+        k = ((unsigned long long)y[i] << 56) | ((unsigned long long)f2key(f) << 24) | (unsigned long long)i;   // i < 2^24
+      }
+      keys[i] = k;
+    }
+    __syncthreads();
+    for (int k2 = 2; k2 <= P2; k2 <<= 1)
+      for (int j = k2 >> 1; j > 0; j >>= 1) {
+        for (int i = tid; i < P2; i += 1024) {
+          const int l = i ^ j;
+          if (l > i) {
+            const bool up = (i & k2) == 0;
+            const unsigned long long a = keys[i], b = keys[l];
+            if ((a > b) == up) { keys[i] = b; keys[l] = a; }
+          }
+        }
+        __syncthreads();
+      }
+    for (int i = tid; i < P; i += 1024) {
+      const unsigned long long k = keys[i];
+      const int c = (int)(k >> 56); const int p = (int)(k & 0xFFFFFFull);
+      const int len = cnt[c], r = i - start[c];
+      if (len < 2) continue;
+      const int half = len / 2;
+      bool selected;
+      if (pass == 0) { const int kk = (int)((double)len * 0.6); selected = r >= kk - half && r < kk; }
+      else selected = r < half;
+      if (selected) w[p] += 1.f / (2.f * half * nclass);
+    }
+    __syncthreads();
+  }
+}
+
+// ---- per-pixel NCE losses + gradient w.r.t. the un-normalised features F (contrast_train.py:261-334)
+//   lane c < 21 owns class c.  sums[0..2] += cross, cross2, intra (already weighted by their means)
+__global__ __launch_bounds__(256) void nce_loss_grad_kernel(const float* __restrict__ fn, const float* __restrict__ nrm, const float* __restrict__ S_own,
+                                                            const float* __restrict__ S_oth, const int* __restrict__ y_own, const int* __restrict__ y_oth,
+                                                            const float* __restrict__ w_intra, const float* __restrict__ p_own, const float* __restrict__ p_oth,
+                                                            float* __restrict__ dF, float* __restrict__ sums, int P, float coef_cross, float coef_intra) {
+  __shared__ float po[21 * 128], pt[21 * 128];
+  __shared__ float red[3][4];
+  for (int i = threadIdx.x; i < 21 * 128; i += 256) { po[i] = p_own[i]; pt[i] = p_oth[i]; }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const float itau = 10.f;                                   // 1 / 0.1
+  float l_cross = 0.f, l_cross2 = 0.f, l_intra = 0.f;
+  for (int p = blockIdx.x * 4 + wv; p < P; p += gridDim.x * 4) {
+    const int yo = y_own[p], yt = y_oth[p];
+    const float so = lane < 21 ? S_own[(size_t)p * 21 + lane] : -INFINITY;
+    const float st = lane < 21 ? S_oth[(size_t)p * 21 + lane] : -INFINITY;
+    const float eo = lane < 21 ? expf(so * itau) : 0.f;
+    const float et = lane < 21 ? expf(st * itau) : 0.f;
+    float sum_o = eo, sum_t = et;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { sum_o += __shfl_xor(sum_o, o, 64); sum_t += __shfl_xor(sum_t, o, 64); }
+    // 1.1 cross-prototype: other view's prototypes, own label;  1.2 cross-pseudo-label: own prototypes, other label
+    const float a_cross = __shfl(et, yo, 64), a_cross2 = __shfl(eo, yt, 64);
+    // 2. intra: own prototypes, own label, negatives = similarity ranks 3..12 (descending, lower index first on ties)
+    int rank = 0;
+    for (int c = 0; c < 21; ++c) { const float sc = __shfl(so, c, 64); if (sc > so || (sc == so && c < lane)) ++rank; }
+    const bool is_neg = lane < 21 && rank >= 3 && rank <= 12;
+    const float a1 = __shfl(eo, yo, 64);
+    float a2 = is_neg ? eo : 0.f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a2 += __shfl_xor(a2, o, 64);
+    a2 += a1;
+    const float wi = w_intra[p];
+    if (lane == 0) {
+      l_cross += -logf(a_cross / sum_t) * coef_cross;
+      l_cross2 += -logf(a_cross2 / sum_o) * coef_cross;
+      if (wi != 0.f) l_intra += -logf(a1 / a2) * wi * coef_intra;
+    }
+    // gradients w.r.t. the similarities
+    float g_t = 0.f, g_o = 0.f;
+    if (lane < 21) {
+      g_t = coef_cross * itau * (et / sum_t - (lane == yo ? 1.f : 0.f));
+      g_o = coef_cross * itau * (eo / sum_o - (lane == yt ? 1.f : 0.f));
+      if (wi != 0.f) {
+        const float mult = (lane == yo ? 1.f : 0.f) + (is_neg ? 1.f : 0.f);
+        g_o += coef_intra * wi * itau * (mult * eo / a2 - (lane == yo ? 1.f : 0.f));
+      }
+    }
+    // d fn = sum_c g_o[c] P_own[c] + g_t[c] P_oth[c]   (lane owns channels lane, lane+64)
+    float da = 0.f, db = 0.f;
+    for (int c = 0; c < 21; ++c) {
+      const float go = __shfl(g_o, c, 64), gt = __shfl(g_t, c, 64);
+      da += go * po[c * 128 + lane] + gt * pt[c * 128 + lane];
+      db += go * po[c * 128 + 64 + lane] + gt * pt[c * 128 + 64 + lane];
+    }
+    const float fa = fn[(size_t)p * 128 + lane], fb = fn[(size_t)p * 128 + 64 + lane];
+    float dot = da * fa + db * fb;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
+    const float nr = nrm[p];
+    const float inv = nr > 1e-12f ? 1.f / nr : 0.f;          // below eps F.normalize divides by a constant: treat as dead
+    dF[(size_t)p * 128 + lane] = (da - fa * dot) * inv;
+    dF[(size_t)p * 128 + 64 + lane] = (db - fb * dot) * inv;
+  }
+  if (lane == 0) { red[0][wv] = l_cross; red[1][wv] = l_cross2; red[2][wv] = l_intra; }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const float t = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+    if (t != 0.f) atomicAdd(&sums[threadIdx.x], t);
+  }
+}
+
+}  // namespace
+
+#define GRID1(total) dim3((unsigned)(((total) + 255) / 256)), dim3(256)
+#define ST ((hipStream_t)stream)
+
+extern "C" int wseg_plane_stats(const float* U, float* stats, long planes, int npix, void* stream) {
+  WSEG_CHECK(U && stats && planes > 0 && npix > 0, "plane_stats: bad arguments");
+  hipLaunchKernelGGL(plane_stats_kernel, dim3((unsigned)planes), dim3(256), 0, ST, U, stats, npix);
+  WSEG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wseg_cls_loss(const float* stats, const float* label20, float* loss_out, float* plane_bias, int N, int npix, float coef, void* stream) {
+  WSEG_CHECK(stats && label20 && loss_out && plane_bias && N > 0, "cls_loss: bad arguments");
+  hipLaunchKernelGGL(cls_loss_kernel, dim3(1), dim3(256), 0, ST, stats, label20, loss_out, plane_bias, N, npix, coef);
+  WSEG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wseg_rvmin_values(const float* U, const float* label20, float* q, unsigned char* argc, int N, int npix, void* stream) {
+  WSEG_CHECK(U && label20 && q && argc && N > 0 && npix > 0, "rvmin_values: bad arguments");
+  const long total = (long)N * npix;
+  hipLaunchKernelGGL(rvmin_values_kernel, GRID1(total), 0, ST, U, label20, q, argc, npix, total);
+  WSEG_LAUNCH_CHECK();
+  return 0;
+}
+
+// k-th order statistic per row + partial sums.  largest=1: the k largest; res[row] = {thr, sum_strict, cnt_strict, cnt_tie}
+// workspace: unsigned state[rows*4] + unsigned hist[rows*256]  (wseg_select_workspace_bytes)
+extern "C" size_t wseg_select_workspace_bytes(int rows) { return (size_t)rows * (4 + 256) * sizeof(unsigned); }
+extern "C" int wseg_select_kth(const float* vals, int rows, int n, int k, int largest, int use_abs, int relu_vals,
+                               float* res, void* workspace, void* stream) {
+  WSEG_CHECK(vals && res && workspace && rows > 0 && n > 0 && k >= 1 && k <= n, "select_kth: bad arguments (rows=%d n=%d k=%d)", rows, n, k);
+  unsigned* state = (unsigned*)workspace;
+  unsigned* hist = state + (size_t)rows * 4;
+  const unsigned rank_small = largest ? (unsigned)(n - k + 1) : (unsigned)k;
+  hipLaunchKernelGGL(select_init_kernel, dim3((rows * 256 + 255) / 256), dim3(256), 0, ST, state, hist, rows, rank_small);
+  const int gx = std::min(256, (n + 2047) / 2048);
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    hipLaunchKernelGGL(select_hist_kernel, dim3(gx, rows), dim3(256), 0, ST, vals, n, use_abs, state, hist, shift);
+    hipLaunchKernelGGL(select_scan_kernel, dim3((rows + 63) / 64), dim3(64), 0, ST, state, hist, shift, rows);
+  }
+  (void)hipMemsetAsync(res, 0, sizeof(float) * 4 * rows, ST);
+  hipLaunchKernelGGL(select_sum_kernel, dim3(gx, rows), dim3(256), 0, ST, vals, n, use_abs, largest, relu_vals, state, res);
+  WSEG_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int wseg_select_finish(const float* res, int rows, int k, int relu_vals, float scale, float* loss_out, void* stream) {
+  WSEG_CHECK(res && loss_out && rows > 0, "select_finish: bad arguments");
+  hipLaunchKernelGGL(select_finish_kernel, dim3(1), dim3(64), 0, ST, res, rows, k, relu_vals, scale, loss_out);
+  WSEG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wseg_rvmin_backward(const float* q, const unsigned char* argc, const float* res, const float* label20, float* dU,
+                                   int N, int npix, int k, float coef, void* stream) {
+  WSEG_CHECK(q && argc && res && label20 && dU, "rvmin_backward: bad arguments");
+  const long total = (long)N * npix;
+  hipLaunchKernelGGL(rvmin_bwd_kernel, GRID1(total), 0, ST, q, argc, res, label20, dU, npix, k, coef, total);
+  WSEG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wseg_norm_resize_forward(const float* U, const float* stats, const float* label20, float* out, int N, int S, int OS, void* stream) {
+  WSEG_CHECK(U && stats && label20 && out && N > 0 && S > 0 && OS > 0, "norm_resize_forward: bad arguments");
+  const long total = (long)N * 21 * OS * OS;
+  hipLaunchKernelGGL(norm_resize_fwd_kernel, GRID1(total), 0, ST, U, stats, label20, out, S, OS, total);
+  WSEG_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int wseg_norm_resize_backward(const float* G, const float* U, const float* stats, const float* label20, float* dU, int N, int S, int OS, void* stream) {
+  WSEG_CHECK(G && U && stats && label20 && dU && N > 0, "norm_resize_backward: bad arguments");
+  hipLaunchKernelGGL(norm_resize_bwd_kernel, dim3(N * 21), dim3(256), 0, ST, G, U, stats, label20, dU, S, OS);
+  WSEG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wseg_er_ecr_prep(const float* c1, const float* c2, const float* r1, const float* r2, float* Gc1, float* Gc2,
+                                float* dlt1, float* dlt2, float* er_sum, int N, int npix, float er_coef, void* stream) {
+  WSEG_CHECK(c1 && c2 && r1 && r2 && Gc1 && Gc2 && dlt1 && dlt2 && er_sum, "er_ecr_prep: bad arguments");
+  const long total = (long)N * npix;
+  hipLaunchKernelGGL(er_ecr_prep_kernel, GRID1(total), 0, ST, c1, c2, r1, r2, Gc1, Gc2, dlt1, dlt2, er_sum, npix, er_coef, total);
+  WSEG_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int wseg_ecr_backward(const float* dlt, const float* res, float* Gr, int N, int per_row, int k, float coef, void* stream) {
+  WSEG_CHECK(dlt && res && Gr, "ecr_backward: bad arguments");
+  const long total = (long)N * per_row;
+  hipLaunchKernelGGL(ecr_bwd_kernel, GRID1(total), 0, ST, dlt, res, Gr, per_row, k, coef, total);
+  WSEG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wseg_rows_resize_forward(const void* head, int ld, float* F, int N, int ih, int iw, int oh, int ow, int dtype, void* stream) {
+  WSEG_CHECK(head && F && ld >= 128, "rows_resize_forward: bad arguments");
+  const long total = (long)N * oh * ow * 128;
+  if (dtype == WSEG_BF16) hipLaunchKernelGGL(rows_resize_fwd_kernel<WSEG_BF16>, GRID1(total), 0, ST, head, ld, F, ih, iw, oh, ow, total);
+  else hipLaunchKernelGGL(rows_resize_fwd_kernel<WSEG_F32>, GRID1(total), 0, ST, head, ld, F, ih, iw, oh, ow, total);
+  WSEG_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int wseg_head_grad_fused(const float* dF, const float* d_cam_low, const void* head, void* d_head, int ld,
+                                    int N, int ih, int iw, int oh, int ow, int dtype, void* stream) {
+  WSEG_CHECK(dF && head && d_head && ld % 8 == 0 && ld >= 152, "head_grad_fused: bad arguments");
+  const long total = (long)N * ih * iw * (ld / 8);
+  if (dtype == WSEG_BF16) hipLaunchKernelGGL(head_grad_fused_kernel<WSEG_BF16>, GRID1(total), 0, ST, dF, d_cam_low, head, d_head, ld, ih, iw, oh, ow, total);
+  else hipLaunchKernelGGL(head_grad_fused_kernel<WSEG_F32>, GRID1(total), 0, ST, dF, d_cam_low, head, d_head, ld, ih, iw, oh, ow, total);
+  WSEG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wseg_pseudo_label(const float* R, const float* label20, float bg_thr, int* y, float* ncam, int N, int npix, void* stream) {
+  WSEG_CHECK(R && label20 && y && ncam && N > 0 && npix > 0, "pseudo_label: bad arguments");
+  hipLaunchKernelGGL(pseudo_label_kernel, dim3(N), dim3(256), 0, ST, R, label20, bg_thr, y, ncam, npix);
+  WSEG_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int wseg_proto_candidates(const float* ncam, const float* F, const int* tie_idx, float* cand_val, float* cand_feat, int* cand_const,
+                                     int N, int npix, int K, void* stream) {
+  WSEG_CHECK(ncam && F && tie_idx && cand_val && cand_feat && cand_const && K >= 1 && K <= 64, "proto_candidates: bad arguments");
+  const size_t P = (size_t)N * npix;
+  WSEG_CHECK(P * 4 <= 128 * 1024 && (size_t)K <= P, "proto_candidates: P=%zu too large for one workgroup's LDS", P);
+  hipLaunchKernelGGL(proto_candidates_kernel, dim3(21), dim3(256), P * 4, ST, ncam, F, tie_idx, cand_val, cand_feat, cand_const, N, npix, K);
+  WSEG_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int wseg_proto_merge(const float* cand_val, const float* cand_feat, const int* cand_const, float* protos, int world, int K, void* stream) {
+  WSEG_CHECK(cand_val && cand_feat && cand_const && protos && world >= 1 && world * K <= 512 && K <= 64, "proto_merge: bad arguments");
+  hipLaunchKernelGGL(proto_merge_kernel, dim3(21), dim3(128), 0, ST, cand_val, cand_feat, cand_const, protos, world, K);
+  WSEG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wseg_nce_sims(const float* F, const float* p_own, const float* p_oth, float* fn, float* nrm, float* S_own, float* S_oth, int P, void* stream) {
+  WSEG_CHECK(F && p_own && p_oth && fn && nrm && S_own && S_oth && P > 0, "nce_sims: bad arguments");
+  hipLaunchKernelGGL(nce_sims_kernel, dim3(std::min(1024, (P + 3) / 4)), dim3(256), 0, ST, F, p_own, p_oth, fn, nrm, S_own, S_oth, P);
+  WSEG_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int wseg_intra_weights(const int* y, const float* S_own, const float* rkey, const unsigned char* rand_flag, float* w, int P, void* stream) {
+  WSEG_CHECK(y && S_own && w && (rkey || rand_flag) && P > 0 && P <= 8192, "intra_weights: needs 0 < P <= 8192 (got %d)", P);
+  int P2 = 1; while (P2 < P) P2 <<= 1;
+  hipLaunchKernelGGL(intra_weights_kernel, dim3(1), dim3(1024), (size_t)P2 * 8, ST, y, S_own, rkey, rand_flag, w, P);
+  WSEG_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int wseg_nce_loss_grad(const float* fn, const float* nrm, const float* S_own, const float* S_oth, const int* y_own, const int* y_oth,
+                                  const float* w_intra, const float* p_own, const float* p_oth, float* dF, float* sums, int P,
+                                  float coef_cross, float coef_intra, void* stream) {
+  WSEG_CHECK(fn && nrm && S_own && S_oth && y_own && y_oth && w_intra && p_own && p_oth && dF && sums && P > 0, "nce_loss_grad: bad arguments");
+  hipLaunchKernelGGL(nce_loss_grad_kernel, dim3(std::min(1024, (P + 3) / 4)), dim3(256), 0, ST, fn, nrm, S_own, S_oth, y_own, y_oth, w_intra, p_own, p_oth,
+                     dF, sums, P, coef_cross, coef_intra);
+  WSEG_LAUNCH_CHECK();
+  return 0;
+}

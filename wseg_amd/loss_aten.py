@@ -61,9 +61,14 @@ def pseudo_labels_and_prototypes(cam_rv_down, f_proj, label, bg_threshold, bg_to
         cam[:, 0, :, :] = bg_threshold
         pseudo = F.softmax(cam * label, dim=1).argmax(dim=1).reshape(-1)
         fea = fea.permute(0, 2, 3, 1).reshape(-1, c_fea)
-        top_values, top_indices = torch.topk(cam.transpose(0, 1).reshape(c, -1), k=h * w // 8, dim=-1)
-        if bg_topk_idx is not None:                     # Q5: the constant bg row's tie order is the CPU library's
-            top_indices[0] = bg_topk_idx.to(top_indices.device)
+        rows_t = cam.transpose(0, 1).reshape(c, -1)
+        top_values, top_indices = torch.topk(rows_t, k=h * w // 8, dim=-1)
+        if bg_topk_idx is not None:
+            # Q5: torch.topk's pick among exactly-tied values is implementation-defined.  The bg row (constant
+            # bg_threshold) and every class that never wins the CAM gate in the batch (constant -1 row) are
+            # fully tied; use the CPU library's data-independent index set for them.
+            const = rows_t.max(dim=1)[0] == rows_t.min(dim=1)[0]
+            top_indices[const] = bg_topk_idx.to(device=top_indices.device, dtype=top_indices.dtype)
         top_fea = fea[top_indices]                                    # [21,32,128]
         protos = (top_values.unsqueeze(-1) * top_fea).sum(1) / top_values.sum(1, keepdim=True)
         protos = F.normalize(protos, dim=-1)

@@ -1,0 +1,192 @@
+"""Fused training-step loss on the HIP kernels (contrast_train.py:138-398).
+
+Drives the kernels of csrc/loss.hip between the two `Engine.run_forward(..., lowres=True)` calls and
+the two `Engine.run_backward` calls: every loss value AND every gradient down to the stride-8 maps is
+computed by hand-written kernels; torch is used for allocation, the RCCL exchange and the final
+combination of a handful of device scalars.  No autograd graph is built.
+
+Global-batch semantics under data parallelism: the per-class top-32 prototype
+candidates (value + feature row) of every rank are all-gathered and merged, so every rank holds the
+prototypes the reference would compute over the whole batch.  Hard-pixel sampling (contrast_train.py
+:302-331) is done per rank (documented deviation: the reference samples over the gathered batch).
+"""
+import torch
+import torch.distributed as dist
+
+from . import _lib as L
+from .engine import HEAD_LD
+
+_TIE_CACHE = {}
+
+
+def cpu_tie_pattern(P, k):
+    """Q5: the index set torch.topk returns for a fully tied row of length P on the CPU library the
+    reference's CPU path uses.  Data independent; computed once per (P, k)."""
+    key = (P, k)
+    if key not in _TIE_CACHE:
+        _TIE_CACHE[key] = torch.topk(torch.full((1, P), 0.2), k, dim=-1)[1][0].to(torch.int32)
+    return _TIE_CACHE[key]
+
+
+def _f32(*shape, dev):
+    return torch.empty(shape, device=dev, dtype=torch.float32)
+
+
+class _View:
+    pass
+
+
+def _maps_forward(v, label20, acc, N):
+    """Upsample, plane statistics, cls + rvmin losses, max-norm + 128x128 resize for one view."""
+    dev = v.cam_low.device
+    S, h, w = v.S, v.h, v.w
+    npix = S * S
+    v.U_cam = _f32(N, 21, S, S, dev=dev)
+    v.U_rv = _f32(N, 21, S, S, dev=dev)
+    L.resize_planar_fwd(v.cam_low, v.U_cam, N * 21, h, w, S, S, True)
+    L.resize_planar_fwd(v.rvd, v.U_rv, N * 21, h, w, S, S, True)
+    v.st_cam = _f32(N * 21, 6, dev=dev)
+    v.st_rv = _f32(N * 21, 6, dev=dev)
+    L.plane_stats(v.U_cam, v.st_cam, N * 21, npix)
+    L.plane_stats(v.U_rv, v.st_rv, N * 21, npix)
+    v.bias = _f32(N * 21, dev=dev)
+    L.cls_loss(v.st_cam, label20, acc[0:1], v.bias, N, npix, 0.5)
+    v.q = _f32(N, npix, dev=dev)
+    v.argc = torch.empty(N, npix, device=dev, dtype=torch.uint8)
+    L.rvmin_values(v.U_rv, label20, v.q, v.argc, N, npix)
+    v.k_min = npix // 4
+    v.res_min = _f32(N, 4, dev=dev)
+    ws = torch.empty(L.select_workspace_bytes(N), device=dev, dtype=torch.uint8)
+    L.select_kth(v.q, N, npix, v.k_min, False, False, True, v.res_min, ws)
+    L.select_finish(v.res_min, N, v.k_min, True, 0.5 / (v.k_min * N), acc[1:2])
+    v.c = _f32(N, 21, 128, 128, dev=dev)
+    v.r = _f32(N, 21, 128, 128, dev=dev)
+    L.norm_resize_forward(v.U_cam, v.st_cam, label20, v.c, N, S, 128)
+    L.norm_resize_forward(v.U_rv, v.st_rv, label20, v.r, N, S, 128)
+
+
+def _maps_backward(v, label20, N):
+    dev = v.cam_low.device
+    S, h, w = v.S, v.h, v.w
+    dU = torch.zeros(N, 21, S, S, device=dev, dtype=torch.float32)
+    L.norm_resize_backward(v.Gc, v.U_cam, v.st_cam, label20, dU, N, S, 128)
+    v.d_cam_low = _f32(N, 21, h, w, dev=dev)
+    L.resize_planar_bwd(dU, v.d_cam_low, N * 21, h, w, S, S, True, plane_add=v.bias)
+    dU.zero_()
+    L.norm_resize_backward(v.Gr, v.U_rv, v.st_rv, label20, dU, N, S, 128)
+    L.rvmin_backward(v.q, v.argc, v.res_min, label20, dU, N, S * S, v.k_min, 0.5 / (v.k_min * N))
+    v.d_rvd = _f32(N, 21, h, w, dev=dev)
+    L.resize_planar_bwd(dU, v.d_rvd, N * 21, h, w, S, S, True)
+
+
+def _prototypes(v, label20, bg_threshold, tie_idx, N, world):
+    dev = v.cam_low.device
+    P = N * 256
+    v.F = _f32(P, 128, dev=dev)
+    L.rows_resize_forward(v.head, HEAD_LD, v.F, N, v.h, v.w, 16, 16)
+    if (v.h, v.w) == (16, 16):
+        R = v.rvd
+    else:
+        R = _f32(N, 21, 16, 16, dev=dev)
+        L.resize_planar_fwd(v.rvd, R, N * 21, v.h, v.w, 16, 16, True)
+    v.y = torch.empty(P, device=dev, dtype=torch.int32)
+    v.ncam = _f32(N, 21, 256, dev=dev)
+    L.pseudo_label(R, label20, bg_threshold, v.y, v.ncam, N, 256)
+    K = 256 // 8
+    cv, cf = _f32(21, K, dev=dev), _f32(21, K, 128, dev=dev)
+    cc = torch.empty(21, device=dev, dtype=torch.int32)
+    L.proto_candidates(v.ncam, v.F, tie_idx, cv, cf, cc, N, 256, K)
+    if world > 1:                                        # global-batch prototypes: exchange candidates over RCCL
+        gv, gf = _f32(world, 21, K, dev=dev), _f32(world, 21, K, 128, dev=dev)
+        gc = torch.empty(world, 21, device=dev, dtype=torch.int32)
+        dist.all_gather_into_tensor(gv, cv)
+        dist.all_gather_into_tensor(gf, cf)
+        dist.all_gather_into_tensor(gc, cc)
+        cv, cf, cc = gv, gf, gc
+    v.protos = _f32(21, 128, dev=dev)
+    L.proto_merge(cv, cf, cc, v.protos, world, K)
+
+
+def _rand_flags(y_dev, rng, P):
+    """RNG-parity mode: the reference's host draws (contrast_train.py:291/:316), as per-pixel flags."""
+    y = y_dev.cpu()
+    for _ in range(P):
+        rng.sample(range(21), 10)
+    flags = torch.zeros(P, dtype=torch.uint8)
+    for cls in torch.unique(y).tolist():
+        members = (y == cls).nonzero(as_tuple=True)[0]
+        n_c = members.numel()
+        if n_c < 2:
+            continue
+        flags[members[torch.tensor(rng.sample(range(n_c), n_c // 2), dtype=torch.long)]] = 1
+    return flags.to(y_dev.device)
+
+
+def step(model, img1, img2, label20, bg_threshold=0.20, rng=None, rng_parity=False, bg_topk_idx=None):
+    """Forward both views, all losses, backward into the engine's flat gradient buffer.
+    Returns the 8 logged scalars (device tensors)."""
+    eng = model._engine
+    dev = img1.device
+    N = img1.shape[0]
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    label20 = label20.to(dev).float().contiguous()
+    eng.ensure_flat(dev)
+    views = []
+    for img in (img1, img2):
+        (cam_low, rvd, _fp, head), S = eng.run_forward(img, save=True, lowres=True)
+        v = _View()
+        v.S, v.h, v.w, v.ctx = img.shape[2], S["h"], S["w"], S
+        v.cam_low, v.rvd, v.head = cam_low, rvd, head
+        views.append(v)
+    v1, v2 = views
+    acc = torch.zeros(8, device=dev, dtype=torch.float32)   # [cls1+cls2, (rvmin1+rvmin2)/2, er_sum, ecr, cross, cross2, intra]
+    for v in views:
+        _maps_forward(v, label20, acc, N)
+    # ---- ER + ECR on the 128x128 maps
+    npix = 128 * 128
+    er_coef = 1.0 / (N * 20 * npix)
+    for v in views:
+        v.Gc = _f32(N, 21, 128, 128, dev=dev)
+    dlt1, dlt2 = _f32(N, 21 * npix, dev=dev), _f32(N, 21 * npix, dev=dev)
+    L.er_ecr_prep(v1.c, v2.c, v1.r, v2.r, v1.Gc, v2.Gc, dlt1, dlt2, acc[2:3], N, npix, er_coef)
+    K_ecr = int(21 * npix * 0.2)
+    ws = torch.empty(L.select_workspace_bytes(N), device=dev, dtype=torch.uint8)
+    for v, dlt in ((v1, dlt1), (v2, dlt2)):
+        res = _f32(N, 4, dev=dev)
+        L.select_kth(dlt, N, 21 * npix, K_ecr, True, True, False, res, ws)
+        L.select_finish(res, N, K_ecr, False, 1.0 / (N * K_ecr), acc[3:4])
+        v.Gr = _f32(N, 21, 128, 128, dev=dev)
+        L.ecr_backward(dlt, res, v.Gr, N, 21 * npix, K_ecr, 1.0 / (N * K_ecr))
+    for v in views:
+        _maps_backward(v, label20, N)
+    # ---- pixel-to-prototype contrast at 16x16
+    P = N * 256
+    tie_idx = (bg_topk_idx if bg_topk_idx is not None else cpu_tie_pattern(P, 32)).to(device=dev, dtype=torch.int32)
+    for v in views:
+        _prototypes(v, label20, bg_threshold, tie_idx, N, world)
+    for v, o in ((v1, v2), (v2, v1)):
+        v.fn, v.nrm = _f32(P, 128, dev=dev), _f32(P, dev=dev)
+        v.S_own, v.S_oth = _f32(P, 21, dev=dev), _f32(P, 21, dev=dev)
+        L.nce_sims(v.F, v.protos, o.protos, v.fn, v.nrm, v.S_own, v.S_oth, P)
+    for v in views:                                        # view 1 fully before view 2 (RNG order of the reference)
+        v.w_intra = _f32(P, dev=dev)
+        if rng_parity:
+            L.intra_weights(v.y, v.S_own, None, _rand_flags(v.y, rng, P), v.w_intra, P)
+        else:
+            L.intra_weights(v.y, v.S_own, torch.rand(P, device=dev), None, v.w_intra, P)
+    for v, o in ((v1, v2), (v2, v1)):
+        v.dF = _f32(P, 128, dev=dev)
+        L.nce_loss_grad(v.fn, v.nrm, v.S_own, v.S_oth, v.y, o.y, v.w_intra, v.protos, o.protos, v.dF, acc[4:7], P,
+                        0.1 / (2 * P), 0.05)
+    # ---- into the network
+    for v in (v2, v1):
+        d_head = torch.empty_like(v.head)
+        L.head_grad_fused(v.dF, v.d_cam_low, v.head, d_head, HEAD_LD, N, v.h, v.w, 16, 16)
+        eng.run_backward(v.ctx, None, v.d_rvd, None, None, d_head_rows=d_head)
+        v.ctx = None
+    loss_cls = acc[0] * 0.5 + acc[1]
+    loss_er = acc[2] * er_coef
+    loss_ecr = acc[3]
+    loss_nce = acc[4] + acc[5] + acc[6]
+    return dict(loss=loss_cls + loss_er + loss_ecr + loss_nce, loss_cls=loss_cls, loss_er=loss_er, loss_ecr=loss_ecr,
+                loss_nce=loss_nce, loss_intra_nce=acc[6], loss_cross_nce=acc[4], loss_cross_nce2=acc[5])
