@@ -60,6 +60,7 @@ typedef struct wseg_conv_desc {
   int32_t mode, epi, dtype;
   int32_t relu_out2;   /* 1: out2 gets the ReLU (default); 0: affine only */
   int32_t relu_lt;     /* epi 0: ReLU on `out` channels < relu_lt (fused head: f_proj | cam); 0 = none */
+  int32_t bm_hint;     /* 0 = library chooses the pixel-tile height (64 for few pixels, else 128); 64 / 128 = force */
 } wseg_conv_desc;
 int wseg_conv_igemm(const wseg_conv_desc* d, void* stream);
 
@@ -76,6 +77,7 @@ typedef struct wseg_wgrad_desc {
   int32_t KH, KW, stride, dil, pad;
   int32_t dtype, split_k;      /* split_k <= 0: library heuristic */
   int32_t IC_dw, OC_dw;        /* real extents of dw ([OC_dw][KH*KW][IC_dw]); IC/OC may be padded */
+  int32_t tile_hint;           /* 0 = library chooses (256x256 tiles for bf16 with OC,IC >= 256), 128 = force 128x128 */
 } wseg_wgrad_desc;
 int wseg_conv_wgrad(const wseg_wgrad_desc* d, void* stream);
 

@@ -26,12 +26,15 @@ CASES = [
     (2, 20, 20, 128, 128, 1, 1, 1),
     (1, 21, 19, 64, 192, 1, 2, 1),
     (1, 9, 9, 256, 24, 1, 1, 1),
+    (1, 13, 11, 256, 512, 3, 1, 2),      # 256x256-tile wgrad path (bf16), odd spatial size
+    (2, 10, 10, 320, 256, 1, 1, 1),      # 256-tile path with an IC tail
 ]
 
 
+@pytest.mark.parametrize("bm", [64, 128])
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("case", CASES)
-def test_conv_fwd_dgrad_wgrad(case, dt):
+def test_conv_fwd_dgrad_wgrad(case, dt, bm):
     from wseg_amd import _lib as L
     N, H, W, IC, OC, k, s, d = case
     tdt = torch.float32 if dt == "f32" else torch.bfloat16
@@ -56,18 +59,19 @@ def test_conv_fwd_dgrad_wgrad(case, dt):
     L.pack_weights(wm, wf, wt, OC, k * k, IC, OC, IC, L.dtype_code(wf))
     # forward
     yg = torch.empty(N, OH, OW, OC, device=dev, dtype=tdt)
-    L.conv_igemm(xg, wf, yg, N=N, IH=H, IW=W, IC=IC, OH=OH, OW=OW, OC=OC, KH=k, KW=k, stride=s, dil=d, pad=pad)
+    L.conv_igemm(xg, wf, yg, N=N, IH=H, IW=W, IC=IC, OH=OH, OW=OW, OC=OC, KH=k, KW=k, stride=s, dil=d, pad=pad, bm_hint=bm)
     np.testing.assert_allclose(yg.float().cpu().numpy(), _nhwc(y.detach()).numpy(), **tol)
     # data gradient (needs OC % (128B/es) == 0 as the reduction dim)
     es = 4 if dt == "f32" else 2
     dyg = _nhwc(dy).to(dev, tdt)
     if (OC * es) % 128 == 0:
         dxg = torch.empty(N, H, W, IC, device=dev, dtype=tdt)
-        L.conv_igemm(dyg, wt, dxg, N=N, IH=OH, IW=OW, IC=OC, OH=H, OW=W, OC=IC, KH=k, KW=k, stride=s, dil=d, pad=pad, mode=1)
+        L.conv_igemm(dyg, wt, dxg, N=N, IH=OH, IW=OW, IC=OC, OH=H, OW=W, OC=IC, KH=k, KW=k, stride=s, dil=d, pad=pad, mode=1, bm_hint=bm)
         np.testing.assert_allclose(dxg.float().cpu().numpy(), _nhwc(x.grad).numpy(), **tol)
     # weight gradient (f32, accumulating)
     dwg = torch.zeros(OC, k * k, IC, device=dev, dtype=torch.float32)
-    L.conv_wgrad(xg, dyg, dwg, N=N, IH=H, IW=W, IC=IC, OH=OH, OW=OW, OC=OC, KH=k, KW=k, stride=s, dil=d, pad=pad)
+    L.conv_wgrad(xg, dyg, dwg, N=N, IH=H, IW=W, IC=IC, OH=OH, OW=OW, OC=OC, KH=k, KW=k, stride=s, dil=d, pad=pad,
+                 tile_hint=256 if bm == 128 else 128)
     ref = w.grad.permute(0, 2, 3, 1).reshape(OC, k * k, IC).numpy()
     scale = np.abs(ref).max()
     wtol = 2e-5 if dt == "f32" else 1e-2

@@ -26,7 +26,7 @@ class ConvDesc(C.Structure):
                 ("ld_rpre", C.c_int32), ("ld_rpost", C.c_int32), ("ld_mask", C.c_int32),
                 ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("dil", C.c_int32), ("pad", C.c_int32),
                 ("mode", C.c_int32), ("epi", C.c_int32), ("dtype", C.c_int32), ("relu_out2", C.c_int32),
-                ("relu_lt", C.c_int32)]
+                ("relu_lt", C.c_int32), ("bm_hint", C.c_int32)]
 
 
 class WgradDesc(C.Structure):
@@ -34,7 +34,8 @@ class WgradDesc(C.Structure):
                 ("N", C.c_int32), ("IH", C.c_int32), ("IW", C.c_int32), ("IC", C.c_int32), ("ld_x", C.c_int32),
                 ("OH", C.c_int32), ("OW", C.c_int32), ("OC", C.c_int32), ("ld_dy", C.c_int32),
                 ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("dil", C.c_int32), ("pad", C.c_int32),
-                ("dtype", C.c_int32), ("split_k", C.c_int32), ("IC_dw", C.c_int32), ("OC_dw", C.c_int32)]
+                ("dtype", C.c_int32), ("split_k", C.c_int32), ("IC_dw", C.c_int32), ("OC_dw", C.c_int32),
+                ("tile_hint", C.c_int32)]
 
 
 def _load():
@@ -75,7 +76,7 @@ def dtype_code(t):
 def conv_igemm(inp, w, out=None, out2=None, *, N, IH, IW, IC, OH, OW, OC, KH, KW, stride=1, dil=1, pad=0,
                mode=0, epi=0, r_pre=None, r_post=None, mask=None, scale=None, shift=None, drop=None,
                ld_in=None, ld_out=None, ld_out2=None, ld_rpre=None, ld_rpost=None, ld_mask=None, relu_out2=1,
-               relu_lt=0):
+               relu_lt=0, bm_hint=0):
     d = ConvDesc()
     d.inp, d.w, d.out, d.out2 = _ptr(inp), _ptr(w), _ptr(out), _ptr(out2)
     d.r_pre, d.r_post, d.mask = _ptr(r_pre), _ptr(r_post), _ptr(mask)
@@ -84,7 +85,7 @@ def conv_igemm(inp, w, out=None, out2=None, *, N, IH, IW, IC, OH, OW, OC, KH, KW
     d.OH, d.OW, d.OC, d.ld_out, d.ld_out2 = OH, OW, OC, ld_out or OC, ld_out2 or OC
     d.ld_rpre, d.ld_rpost, d.ld_mask = ld_rpre or OC, ld_rpost or OC, ld_mask or OC
     d.KH, d.KW, d.stride, d.dil, d.pad = KH, KW, stride, dil, pad
-    d.mode, d.epi, d.dtype, d.relu_out2, d.relu_lt = mode, epi, dtype_code(inp), relu_out2, relu_lt
+    d.mode, d.epi, d.dtype, d.relu_out2, d.relu_lt, d.bm_hint = mode, epi, dtype_code(inp), relu_out2, relu_lt, bm_hint
     if PROFILE is not None:                      # bench.py: HIP events on the launch stream around this launch
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
@@ -97,14 +98,14 @@ def conv_igemm(inp, w, out=None, out2=None, *, N, IH, IW, IC, OH, OW, OC, KH, KW
 
 
 def conv_wgrad(x, dy, dw, *, N, IH, IW, IC, OH, OW, OC, KH, KW, stride=1, dil=1, pad=0,
-               ld_x=None, ld_dy=None, split_k=0, IC_dw=None, OC_dw=None):
+               ld_x=None, ld_dy=None, split_k=0, IC_dw=None, OC_dw=None, tile_hint=0):
     d = WgradDesc()
     d.x, d.dy, d.dw = _ptr(x), _ptr(dy), _ptr(dw)
     d.N, d.IH, d.IW, d.IC, d.ld_x = N, IH, IW, IC, ld_x or IC
     d.OH, d.OW, d.OC, d.ld_dy = OH, OW, OC, ld_dy or OC
     d.KH, d.KW, d.stride, d.dil, d.pad = KH, KW, stride, dil, pad
     d.dtype, d.split_k = dtype_code(x), split_k
-    d.IC_dw, d.OC_dw = IC_dw or IC, OC_dw or OC
+    d.IC_dw, d.OC_dw, d.tile_hint = IC_dw or IC, OC_dw or OC, tile_hint
     assert dw.dtype == torch.float32
     if PROFILE_WGRAD is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

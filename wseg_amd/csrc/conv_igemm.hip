@@ -14,11 +14,9 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, ROWB = 128;      // rows per tile, bytes of K per LDS row
-constexpr int TILE_BYTES = BM * ROWB;              // 16 KiB per operand tile
+constexpr int BN = 128, ROWB = 128;                // out-channel rows per tile, bytes of K per LDS row
+constexpr int B_TILE = BN * ROWB;                  // 16 KiB weight tile
 constexpr int EPI_LD = BN + 4;                     // f32 epilogue image row stride (floats)
-constexpr int SMEM_BYTES = BM * EPI_LD * 4;        // 67584 B  (>= 2 stages * 2 tiles * 16 KiB)
-static_assert(SMEM_BYTES >= 4 * TILE_BYTES, "epilogue image must cover the staging ring");
 
 struct Args {
   wseg_conv_desc d;
@@ -29,8 +27,13 @@ struct Args {
   int nwg;
 };
 
-template <int DT, int EPI>
+// BM = 128 (default) or 64 (few output pixels: twice the workgroups for the same work)
+template <int DT, int EPI, int BM>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const Args a) {
+  constexpr int AI = BM / 32;                      // A pieces per thread per K-step == 16-row MFMA tiles per wave
+  constexpr int A_TILE = BM * ROWB;
+  constexpr int STAGE = A_TILE + B_TILE;
+  constexpr int SMEM_BYTES = (BM * EPI_LD * 4 > 2 * STAGE) ? BM * EPI_LD * 4 : 2 * STAGE;
   constexpr int ES = elem<DT>::size;
   constexpr int CH = 16 / ES;                      // elements per 16-B chunk
   __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
@@ -49,15 +52,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const Args a) {
   // ---- staging assignment: thread -> 4 A rows + 4 B rows, one 16-B chunk each per K-step
   const int srow = lane >> 3;                      // row within an 8-row DMA piece
   const int pch = lane & 7;                        // physical 16-B chunk in the 128-B row
-  int a_iy0[4], a_ix0[4];
-  long a_img[4];                                   // n*IH*IW, or -1 when the row is beyond M
+  int a_iy0[AI], a_ix0[AI];
+  long a_img[AI];                                  // n*IH*IW, or -1 when the row is beyond M
   const char* bptr[4];
   int b_inc[4];
-  int lch[4];                                      // logical chunk this lane fetches for piece i
+  int lch[4];                                      // logical chunk this lane fetches for B piece i
+  int lcha[AI];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = wid * 32 + i * 8 + srow;         // row inside the tile
-    lch[i] = pch ^ ((r >> 1) & 7);
+  for (int i = 0; i < AI; ++i) {
+    const int r = wid * (BM / 4) + i * 8 + srow;   // row inside the A tile
+    lcha[i] = pch ^ ((r >> 1) & 7);
     const int m = m0 + r;
     if (m < a.M) {
       const int hw = d.OH * d.OW;
@@ -69,6 +73,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const Args a) {
     } else {
       a_img[i] = -1; a_iy0[i] = 0; a_ix0[i] = 0;
     }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = wid * 32 + i * 8 + srow;         // row inside the B tile
+    lch[i] = pch ^ ((r >> 1) & 7);
     const int oc = n0 + r;
     if (oc < d.OC) {
       bptr[i] = Wp + ((size_t)oc * a.taps * d.IC + (size_t)lch[i] * CH) * ES;
@@ -77,12 +86,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const Args a) {
       bptr[i] = zero + pch * 16; b_inc[i] = 0;
     }
   }
-  const char* aptr[4];
-  int a_inc[4];
+  const char* aptr[AI];
+  int a_inc[AI];
   auto set_tap = [&](int tap) {
     const int ky = tap / d.KW, kx = tap - ky * d.KW;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < AI; ++i) {
       int iy, ix; bool ok = a_img[i] >= 0;
       if (d.mode == 0) {
         iy = a_iy0[i] + ky * d.dil; ix = a_ix0[i] + kx * d.dil;
@@ -94,7 +103,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const Args a) {
       }
       ok = ok && iy >= 0 && iy < d.IH && ix >= 0 && ix < d.IW;
       if (ok) {
-        aptr[i] = IN + ((size_t)(a_img[i] + (long)iy * d.IW + ix) * d.ld_in + (size_t)lch[i] * CH) * ES;
+        aptr[i] = IN + ((size_t)(a_img[i] + (long)iy * d.IW + ix) * d.ld_in + (size_t)lcha[i] * CH) * ES;
         a_inc[i] = ROWB;
       } else {
         aptr[i] = zero + pch * 16; a_inc[i] = 0;
@@ -103,13 +112,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const Args a) {
   };
 
   auto stage = [&](int buf) {
-    char* la = smem + buf * 2 * TILE_BYTES + wid * 32 * ROWB;
-    char* lb = la + TILE_BYTES;
+    char* la = smem + buf * STAGE + wid * (BM / 4) * ROWB;
+    char* lb = smem + buf * STAGE + A_TILE + wid * 32 * ROWB;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      glds16(aptr[i], la + i * 8 * ROWB);
+      aptr[i] += a_inc[i];
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      glds16(aptr[i], la + i * 8 * ROWB);
       glds16(bptr[i], lb + i * 8 * ROWB);
-      aptr[i] += a_inc[i];
       bptr[i] += b_inc[i];
     }
   };
@@ -118,12 +130,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const Args a) {
   const int wr = wid >> 1, wc = wid & 1;
   const int frow = lane & 15, fk = lane >> 4;
   const int sw = (lane >> 1) & 7;                  // ((row>>1)&7) for row = ...+16*i+frow
-  const int a_rd = (wr * 64 + frow) * ROWB;
-  const int b_rd = TILE_BYTES + (wc * 64 + frow) * ROWB;
+  const int a_rd = (wr * (BM / 2) + frow) * ROWB;
+  const int b_rd = A_TILE + (wc * 64 + frow) * ROWB;
 
-  f32x4 acc[4][4];
+  f32x4 acc[AI][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < AI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -138,33 +150,31 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const Args a) {
       if (++cc == a.cpt) { cc = 0; ++tap; set_tap(tap); }
       stage(cur ^ 1);
     }
-    const char* base = smem + cur * 2 * TILE_BYTES;
+    const char* base = smem + cur * STAGE;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int off = ((ks * 4 + fk) ^ sw) * 16;
       if constexpr (DT == WSEG_BF16) {
-        bf16x8 af[4], bf[4];
+        bf16x8 af[AI], bf[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          af[i] = *reinterpret_cast<const bf16x8*>(base + a_rd + i * 16 * ROWB + off);
-          bf[i] = *reinterpret_cast<const bf16x8*>(base + b_rd + i * 16 * ROWB + off);
-        }
+        for (int i = 0; i < AI; ++i) af[i] = *reinterpret_cast<const bf16x8*>(base + a_rd + i * 16 * ROWB + off);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i) bf[i] = *reinterpret_cast<const bf16x8*>(base + b_rd + i * 16 * ROWB + off);
+#pragma unroll
+        for (int i = 0; i < AI; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
       } else {
-        f32x4 af[4], bf[4];
+        f32x4 af[AI], bf[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          af[i] = *reinterpret_cast<const f32x4*>(base + a_rd + i * 16 * ROWB + off);
-          bf[i] = *reinterpret_cast<const f32x4*>(base + b_rd + i * 16 * ROWB + off);
-        }
+        for (int i = 0; i < AI; ++i) af[i] = *reinterpret_cast<const f32x4*>(base + a_rd + i * 16 * ROWB + off);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bf[i] = *reinterpret_cast<const f32x4*>(base + b_rd + i * 16 * ROWB + off);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
+          for (int i = 0; i < AI; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
               acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
@@ -177,10 +187,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const Args a) {
   // ---- epilogue: accumulators -> LDS f32 image -> coalesced 8-channel vectors
   float* img = reinterpret_cast<float*>(smem);
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < AI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int row = wr * 64 + i * 16 + fk * 4;   // C/D: col = lane&15, row = (lane>>4)*4 + reg
+      const int row = wr * (BM / 2) + i * 16 + fk * 4;   // C/D: col = lane&15, row = (lane>>4)*4 + reg
       const int col = wc * 64 + j * 16 + frow;
 #pragma unroll
       for (int e = 0; e < 4; ++e) img[(row + e) * EPI_LD + col] = acc[i][j][e];
@@ -205,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const Args a) {
   if (has_shift) load8<WSEG_F32>(d.shift, oc, sh);
   constexpr int CHK = 4;
 #pragma unroll 1
-  for (int c0 = 0; c0 < 8; c0 += CHK) {
+  for (int c0 = 0; c0 < BM / 16; c0 += CHK) {
     float rpre[CHK][8], rpost[CHK][8], mk[CHK][8], dr[CHK][8];
     size_t mrow[CHK];
     bool ok[CHK];
@@ -313,11 +323,18 @@ extern "C" int wseg_conv_igemm(const wseg_conv_desc* d, void* stream) {
   a.taps = d->KH * d->KW;
   a.cpt = d->IC * es / ROWB;
   a.ntn = (d->OC + BN - 1) / BN;
-  const long ntm = (M + BM - 1) / BM;
+  // few output pixels (view 2, 16x16 maps): 64-row tiles double the workgroup count
+  const bool small = d->bm_hint == 64 || (d->bm_hint != 128 && ((M + 127) / 128) * a.ntn < 384 && M > 64);
+  const int bm = small ? 64 : 128;
+  const long ntm = (M + bm - 1) / bm;
   a.nwg = (int)(ntm * a.ntn);
   hipStream_t s = (hipStream_t)stream;
   WSEG_CHECK(d->out || d->epi == 0, "conv_igemm: epilogue %d needs `out`", d->epi);
-#define WSEG_LAUNCH_CONV(DT_, EPI_) hipLaunchKernelGGL((conv_igemm_kernel<DT_, EPI_>), dim3(a.nwg), dim3(256), 0, s, a)
+#define WSEG_LAUNCH_CONV(DT_, EPI_)                                                                           \
+  do {                                                                                                        \
+    if (small) hipLaunchKernelGGL((conv_igemm_kernel<DT_, EPI_, 64>), dim3(a.nwg), dim3(256), 0, s, a);       \
+    else hipLaunchKernelGGL((conv_igemm_kernel<DT_, EPI_, 128>), dim3(a.nwg), dim3(256), 0, s, a);            \
+  } while (0)
   if (d->dtype == WSEG_BF16) {
     if (d->epi == 0) WSEG_LAUNCH_CONV(WSEG_BF16, 0); else if (d->epi == 1) WSEG_LAUNCH_CONV(WSEG_BF16, 1); else WSEG_LAUNCH_CONV(WSEG_BF16, 2);
   } else {

@@ -114,33 +114,50 @@ class Engine:
         return scale.contiguous(), shift.contiguous()
 
     def ensure_packs(self, device, dt):
+        """Packed (cast / transposed) weights + folded BatchNorms.  Frozen pieces (every BN, conv1a, b2*) are
+        cached on their own key so a training step only re-packs the 40 trainable tensors."""
         net = self.net
-        key = (dt, str(device), self.flat_w_version) + tuple(p._version for p in net.parameters()) \
-            + tuple(b._version for b in net.buffers())
+        tdt = L.TORCH_DTYPE[dt]
+        frozen_names = [c[0] for b in arch.BLOCKS if b[0] in arch.FROZEN_BLOCKS for c in arch.block_convs(b)]
+        fkey = (dt, str(device)) + tuple(b._version for b in net.buffers()) + \
+            tuple(p._version for n_, p in net.named_parameters() if ".bn" in n_ or n_.startswith("bn7")) + \
+            tuple(self.conv_param(n_)._version for n_ in frozen_names)
+        if getattr(self, "_frozen_packs", None) is None or self._frozen_key != fkey:
+            F_ = {"w": {}, "bn": {}}
+            for b in arch.BLOCKS:
+                for (bname, c) in arch.block_bns(b):
+                    F_["bn"][bname] = self._bn_fold(bname, device)
+                if b[0] in arch.FROZEN_BLOCKS:
+                    for (cname, ci, co, k, s, d) in arch.block_convs(b):
+                        wf = torch.empty(co, k * k, ci, device=device, dtype=tdt)
+                        L.pack_weights(self.conv_param(cname).detach(), wf, None, co, k * k, ci, co, ci, dt)
+                        F_["w"][cname] = wf
+            F_["bn"]["bn7"] = self._bn_fold("bn7", device)
+            self._frozen_packs, self._frozen_key = F_, fkey
+            self.packs = None
+        names = self.trainable_order()
+        key = (dt, str(device), self.flat_w_version) + tuple(self.conv_param(n_)._version for n_ in names)
         if self.packs is not None and key == self.pack_key:
             return self.packs
-        tdt = L.TORCH_DTYPE[dt]
-        P = {"w": {}, "wt": {}, "bn": {}}
+        P = {"w": dict(self._frozen_packs["w"]), "wt": {}, "bn": self._frozen_packs["bn"]}
         no_dgrad = {"b3.conv_branch1", "b3.conv_branch2a"}
         for b in arch.BLOCKS:
+            if b[0] in arch.FROZEN_BLOCKS:
+                continue
             for (cname, ci, co, k, s, d) in arch.block_convs(b):
                 w = self.conv_param(cname).detach()
-                assert w.stride(1) == 1 or k == 1, f"{cname} is not channels_last"
                 T = k * k
                 wf = torch.empty(co, T, ci, device=device, dtype=tdt)
-                need_t = (b[0] not in arch.FROZEN_BLOCKS) and cname not in no_dgrad
-                wt = torch.empty(ci, T, co, device=device, dtype=tdt) if need_t else None
+                wt = torch.empty(ci, T, co, device=device, dtype=tdt) if cname not in no_dgrad else None
                 L.pack_weights(w, wf, wt, co, T, ci, co, ci, dt)
                 P["w"][cname], P["wt"][cname] = wf, wt
-            for (bname, c) in arch.block_bns(b):
-                P["bn"][bname] = self._bn_fold(bname, device)
-        P["bn"]["bn7"] = self._bn_fold("bn7", device)
-        # fused head: rows [fc_proj | fc8 | 0]
+        # fused head: rows [fc_proj | fc8 | 0]; its transposed pack is made from the two f32 masters directly
         wh = torch.zeros(HEAD_LD, 1, 4096, device=device, dtype=tdt)
+        wht = torch.zeros(4096, 1, HEAD_LD, device=device, dtype=tdt)
         L.pack_weights(net.fc_proj.weight.detach(), wh, None, 128, 1, 4096, 128, 4096, dt)
         L.pack_weights(net.fc8.weight.detach(), wh[128:], None, 21, 1, 4096, 21, 4096, dt)
-        wht = torch.empty(4096, 1, HEAD_LD, device=device, dtype=tdt)
-        L.pack_weights(wh.float() if dt == L.BF16 else wh, None, wht, HEAD_LD, 1, 4096, HEAD_LD, 4096, dt)
+        off, _ = self.offsets["fc_proj"]                     # fc_proj and fc8 are adjacent in flat_w: one [149,4096] master
+        L.pack_weights(self.flat_w[off:off + 149 * 4096], None, wht, 149, 1, 4096, HEAD_LD, 4096, dt)
         P["w"]["head"], P["wt"]["head"] = wh, wht
         for nm, (co, ci) in (("f8_3", (64, 512)), ("f8_4", (128, 1024))):
             wf = torch.empty(co, 1, ci, device=device, dtype=tdt)
