@@ -15,6 +15,7 @@
 // K-step moves (BO+BI)*128 B for BO*BI*64 MACs — 64 vs 128 FLOP per byte of L2->LDS fill, which is
 // what bounds this kernel (measured 3.7 GB of fills at 6.4 TB/s for one 512->512 3x3 layer at 128^2).
 // Partial tiles are added to the f32 dW with 256-B-contiguous float atomics.
+#include <stdlib.h>
 #include <algorithm>
 #include "common.h"
 
@@ -24,6 +25,7 @@ struct Args {
   wseg_wgrad_desc d;
   int M, taps, nto, nti, ntiles;
   int pix_per_split;
+  int nsplit, nwg;
 };
 
 template <int DT, int BO, int BI, int WR, int WC>
@@ -48,13 +50,25 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void conv_wgrad_kernel(const Args 
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tile = blockIdx.x;
+  // block -> (tile, pixel split).  All tiles of one split read the same dY / X rows: keep them on ONE XCD
+  // (blocks b and b+8 share an XCD) so the rows are fetched into that XCD's L2 once and every other tile's
+  // LDS-DMA hits L2 (~70 GB/s per CU) instead of MALL/HBM (~25-33 GB/s per CU).
+  int tile, split;
+  if ((a.nsplit & 7) == 0) {
+    const int b = blockIdx.x, xcd = b & 7, j = b >> 3, q = a.nsplit >> 3;
+    tile = j % a.ntiles;
+    split = xcd * q + j / a.ntiles;
+  } else {
+    const int l = xcd_remap(blockIdx.x, a.nwg);           // contiguous logical ids per XCD: the taps of an (oc,ic) tile pair
+    tile = l % a.ntiles;
+    split = l / a.ntiles;
+  }
   const int tap = tile % a.taps;
   const int t2 = tile / a.taps;
   const int ti = t2 % a.nti, to = t2 / a.nti;
   const int oc0 = to * BO, ic0 = ti * BI;
   const int ky = tap / d.KW, kx = tap - ky * d.KW;
-  const int m_begin = blockIdx.y * a.pix_per_split;
+  const int m_begin = split * a.pix_per_split;
   const int m_end = min(a.M, m_begin + a.pix_per_split);
   if (m_begin >= m_end) return;
 
@@ -235,6 +249,180 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void conv_wgrad_kernel(const Args 
   }
 }
 
+// ---- 256x256 bf16 ring variant: 32-pixel K-steps, 4 LDS stages (4 x 32 KiB), THREE steps of LDS-DMA in
+// flight behind a counted s_waitcnt vmcnt(N) + raw s_barrier (a __syncthreads() would drain them with
+// vmcnt(0)).  One barrier per step: it publishes stage kt (every wave's DMA pieces of that stage have
+// landed) and retires stage kt-1 (every wave has consumed its reads), which is the stage the next DMA
+// overwrites.  With one workgroup per CU this is what hides the 2-4 us fill latency.
+__global__ __launch_bounds__(512, 2) void conv_wgrad_ring_kernel(const Args a) {
+  constexpr int BO = 256, BI = 256, WC = 4, NW = 8, NT = 512;
+  constexpr int PK = 32, NS = 4;
+  constexpr int ROWB = 512;                        // 256 channels bf16
+  constexpr int TILE = PK * ROWB;                  // 16 KiB per operand
+  constexpr int STAGE = 2 * TILE;
+  constexpr int MI = 8, NJ = 4;
+  constexpr int EPI_ROWS = 64, EPI_LD = BI + 4;
+  constexpr int SMEM = NS * STAGE;                 // 128 KiB >= epilogue image (66,560 B)
+  constexpr int PP = TILE / 1024 / NW;             // 2 pieces per wave per operand
+  __shared__ __attribute__((aligned(16))) char smem[SMEM];
+  const wseg_wgrad_desc& d = a.d;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int tile, split;
+  if ((a.nsplit & 7) == 0) {
+    const int b = blockIdx.x, xcd = b & 7, j = b >> 3, q = a.nsplit >> 3;
+    tile = j % a.ntiles; split = xcd * q + j / a.ntiles;
+  } else {
+    const int l = xcd_remap(blockIdx.x, a.nwg);
+    tile = l % a.ntiles; split = l / a.ntiles;
+  }
+  const int tap = tile % a.taps;
+  const int t2 = tile / a.taps;
+  const int ti = t2 % a.nti, to = t2 / a.nti;
+  const int oc0 = to * BO, ic0 = ti * BI;
+  const int ky = tap / d.KW, kx = tap - ky * d.KW;
+  const int m_begin = split * a.pix_per_split;
+  const int m_end = min(a.M, m_begin + a.pix_per_split);
+  if (m_begin >= m_end) return;
+  const char* zero = reinterpret_cast<const char*>(g_wseg_zero_page);
+  const char* X = reinterpret_cast<const char*>(d.x);
+  const char* DY = reinterpret_cast<const char*>(d.dy);
+
+  int rr[PP], lc[PP], cn[PP], cy[PP], cx[PP];
+  bool xok[PP], yok[PP];
+#pragma unroll
+  for (int i = 0; i < PP; ++i) {
+    const int ci = (wid * PP + i) * 64 + lane;     // physical chunk index in the tile (32 chunks per row)
+    rr[i] = ci >> 5;
+    const int pch = ci & 31, blk = pch >> 1;
+    const int sw = (rr[i] & 3) | (((rr[i] >> 3) & 1) << 2);
+    lc[i] = (((blk & ~7) | ((blk ^ sw) & 7)) << 1) | (pch & 1);
+    xok[i] = (ic0 + lc[i] * 8) < d.IC;
+    yok[i] = (oc0 + lc[i] * 8) < d.OC;
+    const int m = m_begin + rr[i];
+    const int hw = d.OH * d.OW;
+    const int n = m / hw, rem = m - n * hw;
+    cn[i] = n; cy[i] = rem / d.OW; cx[i] = rem - cy[i] * d.OW;
+  }
+  auto stage = [&](int buf, int mstep) {
+    char* lo = smem + buf * STAGE;
+    char* li = lo + TILE;
+#pragma unroll
+    for (int i = 0; i < PP; ++i) {
+      const int m = mstep + rr[i];
+      const char* po = zero + (lane & 15) * 16;
+      const char* pi = po;
+      if (m < m_end) {
+        if (yok[i]) po = DY + ((size_t)m * d.ld_dy + oc0 + lc[i] * 8) * 2;
+        if (xok[i]) {
+          const int iy = cy[i] * d.stride + ky * d.dil - d.pad;
+          const int ix = cx[i] * d.stride + kx * d.dil - d.pad;
+          if (iy >= 0 && iy < d.IH && ix >= 0 && ix < d.IW)
+            pi = X + ((size_t)((cn[i] * d.IH + iy) * d.IW + ix) * d.ld_x + ic0 + lc[i] * 8) * 2;
+        }
+      }
+      glds16(po, lo + (wid * PP + i) * 1024);
+      glds16(pi, li + (wid * PP + i) * 1024);
+      cx[i] += PK;
+      while (cx[i] >= d.OW) { cx[i] -= d.OW; if (++cy[i] == d.OH) { cy[i] = 0; ++cn[i]; } }
+    }
+  };
+
+  const int wr = wid / WC, wc = wid % WC;
+  const int fcol = lane & 15, fk = lane >> 4;
+  const int q = (lane & 15) >> 2, p = lane & 3;
+  f32x4 acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // per-lane byte offsets of the transposed reads inside a stage (row h*4+q of k-group fk, swizzled 32-B block)
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  unsigned off_o[2][MI], off_i[2][NJ];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int row = fk * 8 + h * 4 + q;
+    const int sw = (row & 3) | (((row >> 3) & 1) << 2);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) { const int blk = wr * MI + i; off_o[h][i] = row * ROWB + (((blk & ~7) | ((blk ^ sw) & 7)) << 5) + p * 8; }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) { const int blk = wc * NJ + j; off_i[h][j] = row * ROWB + (((blk & ~7) | ((blk ^ sw) & 7)) << 5) + p * 8; }
+  }
+  const int nk = (m_end - m_begin + PK - 1) / PK;
+  // prologue: steps 0..2 in flight (4 LDS-DMA instructions per thread per step)
+  stage(0, m_begin);
+  if (nk > 1) stage(1, m_begin + PK);
+  if (nk > 2) stage(2, m_begin + 2 * PK);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int ahead = min(2, nk - 1 - kt);          // steps issued after step kt and still allowed in flight
+    if (ahead == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + 3 < nk) stage((kt + 3) & 3, m_begin + (kt + 3) * PK);
+    // transposed fragment reads through inline asm: hipcc's waitcnt pass would otherwise put vmcnt(0) in
+    // front of the first LDS read of every step (it cannot tell the reads from the in-flight LDS-DMA).
+    const unsigned sbase = lds0 + (unsigned)(kt & 3) * STAGE;
+    bf16x4 vo[2][MI], vi[2][NJ];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(vo[h][i]) : "v"(sbase + off_o[h][i]));
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(vi[h][j]) : "v"(sbase + TILE + off_i[h][j]));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8 af[MI], bf[NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { af[i][e] = vo[0][i][e]; af[i][4 + e] = vo[1][i][e]; }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { bf[j][e] = vi[0][j][e]; bf[j][4 + e] = vi[1][j][e]; }
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+  }
+  __syncthreads();
+
+  float* img = reinterpret_cast<float*>(smem);
+  const size_t row_stride = (size_t)a.taps * d.IC_dw;
+#pragma unroll 1
+  for (int ps = 0; ps < BO / EPI_ROWS; ++ps) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int t = wr * MI + i;
+      if (t / 4 == ps) {
+        const int row = (t % 4) * 16 + fk * 4;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int col = (wc * NJ + j) * 16 + fcol;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) img[(row + e) * EPI_LD + col] = acc[i][j][e];
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int idx = tid; idx < EPI_ROWS * BI; idx += NT) {
+      const int row = idx / BI, col = idx - row * BI;
+      const int oc = oc0 + ps * EPI_ROWS + row, ic = ic0 + col;
+      if (oc < d.OC_dw && ic < d.IC_dw)
+        atomicAdd(&d.dw[(size_t)oc * row_stride + (size_t)tap * d.IC_dw + ic], img[row * EPI_LD + col]);
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace
 
 extern "C" int wseg_conv_wgrad(const wseg_wgrad_desc* d, void* stream) {
@@ -257,21 +445,37 @@ extern "C" int wseg_conv_wgrad(const wseg_wgrad_desc* d, void* stream) {
   a.nto = (d->OC + BO - 1) / BO;
   a.nti = (d->IC + BI - 1) / BI;
   a.ntiles = a.nto * a.nti * a.taps;
-  const int pk = d->dtype == WSEG_BF16 ? 64 : 32;
+  const int pk = d->dtype == WSEG_BF16 ? 64 : 32;       // (the ring variant steps by 32: 64 is a multiple)
   int split = d->split_k;
-  if (split <= 0) {                            // heuristic: fill the chip (>= 2 / 1 workgroups per CU), >= 8 K-steps each
-    const int want = big ? 256 : 512;
-    split = (want + a.ntiles - 1) / a.ntiles;
-    const int max_split = (int)std::max(1L, M / (pk * 8));
-    split = std::max(1, std::min(split, max_split));
+  if (split <= 0) {
+    // pick the split that minimises  rounds x (K-steps per workgroup + epilogue cost):  a tile count that is
+    // not a multiple of the resident-workgroup slots otherwise leaves a nearly empty last round
+    // (36 tiles x 8 splits = 288 workgroups on 256 single-workgroup CUs ran two rounds).
+    const long slots = big ? 256 : 512;
+    const double epi = big ? 28.0 : 10.0;          // epilogue (LDS image + float atomics) in K-step units
+    const int max_split = (int)std::max(1L, std::min(64L, M / (pk * 8)));
+    double best = 1e30;
+    split = 1;
+    for (int sp = 1; sp <= max_split; ++sp) {
+      const long blocks = (long)a.ntiles * sp;
+      const long rounds = (blocks + slots - 1) / slots;
+      const double steps = (double)((M + sp - 1) / sp + pk - 1) / pk;
+      const double cost = rounds * (steps + epi) * (1.0 + 0.002 * sp);     // mild preference for fewer partial sums
+      if (cost < best) { best = cost; split = sp; }
+    }
   }
   long pps = (M + split - 1) / split;
   pps = (pps + pk - 1) / pk * pk;
   a.pix_per_split = (int)pps;
   split = (int)((M + pps - 1) / pps);
+  a.nsplit = split;
+  a.nwg = a.ntiles * split;
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid(a.ntiles, split);
-  if (big)
+  dim3 grid(a.nwg);
+  static const bool use_ring = getenv("WSEG_WGRAD_RING") && getenv("WSEG_WGRAD_RING")[0] == '1';   // opt-in: measured equal to the 2-stage kernel
+  if (big && use_ring)
+    hipLaunchKernelGGL(conv_wgrad_ring_kernel, grid, dim3(512), 0, s, a);
+  else if (big)
     hipLaunchKernelGGL((conv_wgrad_kernel<WSEG_BF16, 256, 256, 2, 4>), grid, dim3(512), 0, s, a);
   else if (d->dtype == WSEG_BF16)
     hipLaunchKernelGGL((conv_wgrad_kernel<WSEG_BF16, 128, 128, 2, 2>), grid, dim3(256), 0, s, a);
