@@ -114,8 +114,14 @@ int wseg_planar_to_rows(const float* planar, void* rows, int ld, int c0, int C, 
  * 0/1 — resnet38_contrast.py:57-59, contrast_train.py:131-134,145-152,180; contrast_infer.py:62).
  * bwd is the exact adjoint computed by gather (deterministic). plane_mul (nullable) scales plane p;
  * plane_add (nullable, bwd) is a constant added to every d_out element of plane p (the GAP gradient). */
-int wseg_resize_planar_fwd(const float* in, float* out, const float* plane_mul, long planes, int ih, int iw, int oh, int ow, int align, void* stream);
+int wseg_resize_planar_fwd(const float* in, float* out, const float* plane_mul, long planes, int ih, int iw, int oh, int ow, int align,
+                           int flip_x, int accumulate, void* stream);   /* flip_x: out[..,x] = resized[..,ow-1-x]; accumulate: out += */
 int wseg_resize_planar_bwd(const float* d_out, float* d_in, const float* plane_mul, const float* plane_add, long planes, int ih, int iw, int oh, int ow, int align, int accumulate, void* stream);
+
+/* inference post-process, contrast_infer.py:75-98: sum of 8 label-gated CAMs -> clamp, per-class
+ * (x-min-1e-5)/(max-min+1e-5) with entries < min+1e-5 zeroed first, argmax against the constant bg score alpha.
+ * stats = wseg_plane_stats(sum_cam, 20 planes). */
+int wseg_infer_finish(const float* sum_cam, const float* stats, float alpha, float* norm_cam, unsigned char* pred, int npix, void* stream);
 
 /* ---- PCM (network/resnet38_contrast.py:63-75), flash-style, exact-f32 MFMA ---------------------
  * l2norm  : Fh = F/(||F||_2 + 1e-5) over the 192 f9 channels of each pixel row (:70)

@@ -1,0 +1,116 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every symbol include/wseg_hip.h declares,
+the PolyOptimizer host logic matches the reference fixture, and the VOC-format host plumbing parses the
+reference's file formats.  No compute kernel is called."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "wseg_amd", "libwseg_hip.so")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(LIB):
+        subprocess.check_call(["bash", os.path.join(ROOT, "wseg_amd", "csrc", "build.sh")])
+    return ctypes.CDLL(LIB)
+
+
+def test_cabi_exports_every_declared_symbol(lib):
+    header = open(os.path.join(ROOT, "include", "wseg_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(wseg_[a-z0-9_]+)\s*\(", header)))
+    assert len(declared) >= 35
+    missing = [s for s in declared if not hasattr(lib, s)]
+    assert not missing, missing
+    lib.wseg_version.restype = ctypes.c_int
+    assert lib.wseg_version() >= 100
+    lib.wseg_last_error.restype = ctypes.c_char_p
+    assert isinstance(lib.wseg_last_error(), bytes)
+
+
+def test_cabi_rejects_bad_descriptor_without_touching_a_gpu(lib):
+    from wseg_amd import _lib as L
+    d = L.ConvDesc()                      # all-null descriptor: the host-side shape check must refuse it
+    assert lib.wseg_conv_igemm(ctypes.byref(d), None) != 0
+    assert b"null" in lib.wseg_last_error()
+    w = L.WgradDesc()
+    assert lib.wseg_conv_wgrad(ctypes.byref(w), None) != 0
+
+
+def test_poly_optimizer_matches_reference_fixture(golden_dir, lib):
+    """wseg_amd.optim.PolyOptimizer on plain (non flat-backed) CPU parameters takes the torch.optim.SGD route:
+    the momentum quirk, per-group weight decay, poly LR and `global_step` must match tool/torchutils.py:11-33."""
+    from wseg_amd.optim import PolyOptimizer
+    g = np.load(os.path.join(golden_dir, "sgd_3steps.npz"))
+    ps = [torch.nn.Parameter(torch.from_numpy(g[f"p{i}_init"]).clone()) for i in range(3)]
+    opt = PolyOptimizer([{"params": [ps[0]], "lr": 0.01, "weight_decay": 5e-4}, {"params": [ps[1]], "lr": 0.02, "weight_decay": 0},
+                         {"params": [ps[2]], "lr": 0.1, "weight_decay": 5e-4}, {"params": [], "lr": 0.2, "weight_decay": 0}],
+                        lr=0.01, weight_decay=5e-4, max_step=10)
+    assert opt.param_groups[0]["momentum"] == 5e-4
+    for s in range(3):
+        for i, p in enumerate(ps):
+            p.grad = torch.from_numpy(g[f"g{s}_{i}"]).clone()
+        if s == 1:
+            ps[1].grad = None
+        opt.step()
+    assert opt.global_step == 3
+    for i in range(3):
+        np.testing.assert_allclose(ps[i].detach().numpy(), g[f"p{i}_final"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose([gr["lr"] for gr in opt.param_groups], g["lr_final"], rtol=1e-12)
+
+
+def test_net_module_contract(lib):
+    """Constructor, state_dict names/shapes, parameter groups and train() freezing — no forward."""
+    import contextlib
+    import io
+    from wseg_amd import arch
+    from wseg_amd.resnet38_contrast import Net
+    m = Net(precision="fp32")
+    spec = arch.state_dict_spec()
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(spec.keys()) and len(sd) == 233
+    assert all(tuple(sd[k].shape) == tuple(spec[k]) for k in sd)
+    with contextlib.redirect_stdout(io.StringIO()):
+        groups = m.get_parameter_groups()
+    assert [len(x) for x in groups] == [43, 0, 5, 0]
+    m.train()
+    assert sum(1 for p in m.parameters() if p.requires_grad) == 40
+    assert sum(p.numel() for p in m.parameters() if p.requires_grad) == 105013824
+    assert not any(mod.training for mod in m.modules() if isinstance(mod, torch.nn.BatchNorm2d))
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 3, 32, 32))                       # no CPU fallback
+
+
+def test_voc_host_plumbing(tmp_path, lib):
+    import PIL.Image
+    from wseg_amd import data as wdata
+    from wseg_amd.resnet38_contrast import Normalize
+    root = tmp_path / "VOC2012"
+    (root / "JPEGImages").mkdir(parents=True)
+    names = ["2007_000032", "2007_000039", "2008_000123"]
+    rng = np.random.default_rng(0)
+    for i, n in enumerate(names):
+        PIL.Image.fromarray(rng.integers(0, 256, (60 + 10 * i, 90, 3), dtype=np.uint8)).save(root / "JPEGImages" / (n + ".jpg"))
+    lst = tmp_path / "train.txt"
+    lst.write_text("\n".join(f"/JPEGImages/{n}.jpg /SegmentationClassAug/{n}.png" for n in names) + "\n")
+    labels = {n: np.eye(20, dtype=np.float32)[i] for i, n in enumerate(names)}
+    np.save(tmp_path / "cls_labels.npy", labels, allow_pickle=True)
+    assert wdata.load_img_name_list(str(lst)) == names
+    norm = Normalize()
+    model_stub = type("M", (), {"normalize": norm})()
+    ds = wdata.VOC12ClsDataset(str(lst), str(root), str(tmp_path / "cls_labels.npy"), wdata.train_transform(model_stub, 64))
+    name, img, lab = ds[1]
+    assert name == names[1] and tuple(img.shape) == (3, 64, 64) and img.dtype == torch.float32 and lab[1] == 1
+    msf = wdata.VOC12ClsDatasetMSF(str(lst), str(root), str(tmp_path / "cls_labels.npy"), scales=[0.5, 1.0, 1.5, 2.0],
+                                   inter_transform=[np.asarray, norm, wdata.HWC_to_CHW])
+    name, imgs, lab = msf[0]
+    assert len(imgs) == 8 and imgs[0].shape == (3, 30, 45) and imgs[6].shape == (3, 120, 180)
+    np.testing.assert_array_equal(imgs[3], np.flip(imgs[2], -1))
+    x = norm(np.full((2, 2, 3), 255, np.uint8))
+    np.testing.assert_allclose(x[0, 0], [(1 - 0.485) / 0.229, (1 - 0.456) / 0.224, (1 - 0.406) / 0.225], rtol=1e-6)

@@ -151,8 +151,12 @@ def head_grad_rows(d_fproj, d_cam_low, head, d_head, ld, N, hw):
     check(lib.wseg_head_grad_rows(_v(d_fproj), _v(d_cam_low), _v(head), _v(d_head), ld, N, hw, dtype_code(head), _s()), "wseg_head_grad_rows")
 
 
-def resize_planar_fwd(inp, out, planes, ih, iw, oh, ow, align, plane_mul=None):
-    check(lib.wseg_resize_planar_fwd(_v(inp), _v(out), _v(plane_mul), C.c_long(planes), ih, iw, oh, ow, int(align), _s()), "wseg_resize_planar_fwd")
+def resize_planar_fwd(inp, out, planes, ih, iw, oh, ow, align, plane_mul=None, flip_x=False, accumulate=False):
+    check(lib.wseg_resize_planar_fwd(_v(inp), _v(out), _v(plane_mul), C.c_long(planes), ih, iw, oh, ow, int(align), int(flip_x), int(accumulate), _s()), "wseg_resize_planar_fwd")
+
+
+def infer_finish(sum_cam, stats, alpha, norm_cam, pred, npix):
+    check(lib.wseg_infer_finish(_v(sum_cam), _v(stats), C.c_float(alpha), _v(norm_cam), _v(pred), npix, _s()), "wseg_infer_finish")
 
 
 def resize_planar_bwd(d_out, d_in, planes, ih, iw, oh, ow, align, accumulate=False, plane_mul=None, plane_add=None):

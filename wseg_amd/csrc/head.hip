@@ -90,10 +90,11 @@ __global__ void pcm_xs_kernel(const float* __restrict__ x, void* __restrict__ fe
 
 // ---- planar bilinear resize [planes][ih][iw] -> [planes][oh][ow], optional per-plane multiplier
 __global__ void resize_planar_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ plane_mul,
-                                         int ih, int iw, int oh, int ow, int align, long total) {
+                                         int ih, int iw, int oh, int ow, int align, int flip_x, int accumulate, long total) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
-  const int ox = (int)(idx % ow); const long r = idx / ow;
+  int ox = (int)(idx % ow); const long r = idx / ow;
+  if (flip_x) ox = ow - 1 - ox;                            // out[.., x] = resized[.., ow-1-x]  (np.flip(cam, -1))
   const int oy = (int)(r % oh); const long pl = r / oh;
   int y0, y1, x0, x1; float fy, fx;
   src_index(oy, resize_scale(ih, oh, align), align, ih, y0, y1, fy);
@@ -102,7 +103,25 @@ __global__ void resize_planar_fwd_kernel(const float* __restrict__ in, float* __
   float v = (1.f - fy) * ((1.f - fx) * p[(size_t)y0 * iw + x0] + fx * p[(size_t)y0 * iw + x1]) +
             fy * ((1.f - fx) * p[(size_t)y1 * iw + x0] + fx * p[(size_t)y1 * iw + x1]);
   if (plane_mul) v *= plane_mul[pl];
-  out[idx] = v;
+  if (accumulate) out[idx] += v; else out[idx] = v;
+}
+
+// ---- inference post-process (contrast_infer.py:75-98): clamp, per-class min/max normalise, argmax vs alpha
+//      stats = plane_stats of sum_cam (max/min of relu == clamp-then-max/min)
+__global__ void infer_finish_kernel(const float* __restrict__ sum_cam, const float* __restrict__ stats, float alpha,
+                                    float* __restrict__ norm_cam, unsigned char* __restrict__ pred, int npix) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= npix) return;
+  float best = alpha; int bc = 0;
+  for (int c = 0; c < 20; ++c) {
+    float v = fmaxf(sum_cam[(size_t)c * npix + p], 0.f);
+    const float mx = stats[c * 6 + 0], mn = stats[c * 6 + 1];
+    if (v < mn + 1e-5f) v = 0.f;
+    v = (v - mn - 1e-5f) / (mx - mn + 1e-5f);
+    norm_cam[(size_t)c * npix + p] = v;
+    if (v > best) { best = v; bc = c + 1; }
+  }
+  pred[p] = (unsigned char)bc;
 }
 
 // exact adjoint by GATHER (deterministic, no atomics): d_in[y][x] = sum over outputs that touch it
@@ -204,10 +223,11 @@ extern "C" int wseg_pcm_xs(const float* x_nchw, void* feat, int ld, int c_xs, in
   return 0;
 }
 
-extern "C" int wseg_resize_planar_fwd(const float* in, float* out, const float* plane_mul, long planes, int ih, int iw, int oh, int ow, int align, void* stream) {
+extern "C" int wseg_resize_planar_fwd(const float* in, float* out, const float* plane_mul, long planes, int ih, int iw, int oh, int ow, int align,
+                                      int flip_x, int accumulate, void* stream) {
   WSEG_CHECK(in && out && planes > 0 && ih > 0 && iw > 0 && oh > 0 && ow > 0, "resize_planar_fwd: bad arguments");
   const long total = planes * oh * ow;
-  hipLaunchKernelGGL(resize_planar_fwd_kernel, GRID1(total), 0, (hipStream_t)stream, in, out, plane_mul, ih, iw, oh, ow, align, total);
+  hipLaunchKernelGGL(resize_planar_fwd_kernel, GRID1(total), 0, (hipStream_t)stream, in, out, plane_mul, ih, iw, oh, ow, align, flip_x, accumulate, total);
   WSEG_LAUNCH_CHECK();
   return 0;
 }
@@ -234,6 +254,13 @@ extern "C" int wseg_head_grad_rows(const float* d_fproj, const float* d_cam_low,
   const long total = (long)N * hw * (ld / 8);
   if (dtype == WSEG_BF16) hipLaunchKernelGGL(head_grad_rows_kernel<WSEG_BF16>, GRID1(total), 0, (hipStream_t)stream, d_fproj, d_cam_low, head, d_head, ld, hw, total);
   else hipLaunchKernelGGL(head_grad_rows_kernel<WSEG_F32>, GRID1(total), 0, (hipStream_t)stream, d_fproj, d_cam_low, head, d_head, ld, hw, total);
+  WSEG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wseg_infer_finish(const float* sum_cam, const float* stats, float alpha, float* norm_cam, unsigned char* pred, int npix, void* stream) {
+  WSEG_CHECK(sum_cam && stats && norm_cam && pred && npix > 0, "infer_finish: bad arguments");
+  hipLaunchKernelGGL(infer_finish_kernel, GRID1((long)npix), 0, (hipStream_t)stream, sum_cam, stats, alpha, norm_cam, pred, npix);
   WSEG_LAUNCH_CHECK();
   return 0;
 }

@@ -1,0 +1,35 @@
+"""Multi-scale CAM inference of contrast_infer.py:58-99 on the HIP kernels.
+
+8 forwards (4 scales x {orig, h-flip}); output #2 of the Net (the PCM-refined CAM); bilinear resize to
+the original size (align_corners=False), label gating, un-flip and the sum are ONE accumulate kernel per
+forward; clamp / per-class min-max normalise / argmax against the bg score are fused in `infer_finish`.
+"""
+import torch
+
+from . import _lib as L
+
+
+@torch.no_grad()
+def infer_image(model, img_list, label20, orig_size, alpha=0.26):
+    """img_list: 8 float tensors [1,3,h,w] (or [3,h,w]) in VOC12ClsDatasetMSF order; label20 [20];
+    returns (norm_cam [20,H,W] f32, pred [H,W] uint8, cam_dict {class: map}) — device tensors."""
+    dev = next(model.parameters()).device
+    H, W = orig_size
+    lab = label20.to(dev).float().contiguous()
+    sum_cam = torch.zeros(20, H, W, device=dev, dtype=torch.float32)
+    for i, img in enumerate(img_list):
+        img = torch.as_tensor(img).to(dev).float()
+        if img.dim() == 3:
+            img = img.unsqueeze(0)
+        _, cam_rv, _, _ = model(img.contiguous())
+        hs, ws = cam_rv.shape[2], cam_rv.shape[3]
+        # planes 1..20 of image 0 (contrast_infer.py:62 `cam[:, 1:, :, :]`, `[0]`)
+        L.resize_planar_fwd(cam_rv[0, 1:].contiguous(), sum_cam, 20, hs, ws, H, W, False, plane_mul=lab,
+                            flip_x=(i % 2 == 1), accumulate=True)
+    stats = torch.empty(20, 6, device=dev, dtype=torch.float32)
+    L.plane_stats(sum_cam, stats, 20, H * W)
+    norm_cam = torch.empty(20, H, W, device=dev, dtype=torch.float32)
+    pred = torch.empty(H, W, device=dev, dtype=torch.uint8)
+    L.infer_finish(sum_cam, stats, alpha, norm_cam, pred, H * W)
+    cam_dict = {i: norm_cam[i] for i in range(20) if float(label20[i]) > 1e-5}
+    return norm_cam, pred, cam_dict

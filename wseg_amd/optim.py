@@ -23,7 +23,7 @@ class PolyOptimizer(torch.optim.SGD):
         self.__initial_lr = [group['lr'] for group in self.param_groups]
         self._flat_buf = None
         self._flat_first = True
-        self.grad_scale = 1.0
+        self.wseg_grad_scale = 1.0
 
     def _poly(self):
         if self.global_step < self.max_step:
@@ -78,7 +78,7 @@ class PolyOptimizer(torch.optim.SGD):
                 self._flat_buf = torch.empty_like(eng.flat_w)
                 self._flat_first = True
             L.sgd_step(eng.flat_w, eng.flat_g, self._flat_buf, [(s[0], s[1], s[2], s[3]) for s in segs],
-                       segs[0][4], self.grad_scale, self._flat_first)
+                       segs[0][4], self.wseg_grad_scale, self._flat_first)
             self._flat_first = False
             eng.flat_w_version += 1
         self.global_step += 1

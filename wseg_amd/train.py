@@ -54,6 +54,6 @@ class Trainer:
         if self.world > 1:
             eng = model._engine
             dist.all_reduce(eng.flat_g)                     # RCCL over xGMI; averaged by grad_scale below
-            opt.grad_scale = 1.0 / self.world
+            opt.wseg_grad_scale = 1.0 / self.world
         opt.step()
         return {k: v.detach() for k, v in losses.items()}
