@@ -27,7 +27,7 @@ def conv_flops_model():
     return 2.4292e12
 
 
-def cpu_baseline(sample_n=1, size=448):
+def cpu_baseline(sample_n=2, size=448):
     """The oracle (CPU restatement, pinned to the reference) timed on this box's host cores."""
     import random
     from oracle import loss as oloss
@@ -58,7 +58,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--size", type=int, default=448)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--loss", default=os.environ.get("WSEG_LOSS", "aten"))
+    ap.add_argument("--loss", default=os.environ.get("WSEG_LOSS", "hip"), choices=["hip", "aten"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lr", type=float, default=1e-5,
                     help="base lr; the reference's 0.01 makes the RANDOM procedural weights diverge within 2 steps "

@@ -14,7 +14,7 @@ lr = 1e-5
 opt = PolyOptimizer([{'params': groups[0], 'lr': lr, 'weight_decay': 5e-4}, {'params': groups[1], 'lr': 2*lr, 'weight_decay': 0},
                      {'params': groups[2], 'lr': 10*lr, 'weight_decay': 5e-4}, {'params': groups[3], 'lr': 20*lr, 'weight_decay': 0}], lr=lr, weight_decay=5e-4, max_step=5000)
 model.load_state_dict(synth.procedural_state_dict(0, device=dev)); model.cuda(); model.train()
-tr = Trainer(model, opt, 0.20, random.Random(0), False, os.environ.get("WSEG_LOSS", "aten"))
+tr = Trainer(model, opt, 0.20, random.Random(0), False, os.environ.get("WSEG_LOSS", "hip"))
 img = synth.synthetic_images(16, 448, 0, dev); lab = synth.synthetic_labels(16, 0, dev)
 for _ in range(2): tr.step(img, lab)
 L.PROFILE, L.PROFILE_WGRAD = [], []

@@ -49,33 +49,42 @@ template <int DT>
 __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                    const float* __restrict__ scale, const float* __restrict__ shift,
                                                    void* raw, void* act, int N, int H, int W) {
-  __shared__ float ws[64 * 27];
-  __shared__ __attribute__((aligned(16))) float tile[64 * 64];      // [px][oc] staging for coalesced stores
+  // 64 pixels of one image row x 64 output channels per workgroup; wave `cg` owns channels [16cg, 16cg+16):
+  // its weight index is wave-uniform, so the 432 weights come through the scalar cache (s_load) and feed
+  // v_fmac as SGPR operands — no LDS traffic in the FMA loop.  Output goes through an LDS tile so the NHWC
+  // stores are full 16-B vectors of consecutive channels.
+  __shared__ __attribute__((aligned(16))) float tile[64 * 68];      // [px][oc], row padded by 4 floats
   const int tid = threadIdx.x;
-  for (int i = tid; i < 64 * 27; i += 256) ws[i] = w[i];
   const int nxb = (W + 63) / 64;
   const int bx = blockIdx.x % nxb;
   const int y = (blockIdx.x / nxb) % H;
   const int n = blockIdx.x / (nxb * H);
   const int px = tid & 63, cg = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int xg = bx * 64 + px;
-  __syncthreads();
-  float acc[16];
+  float in[27];
 #pragma unroll
-  for (int o = 0; o < 16; ++o) acc[o] = 0.f;
-  // same (ic, ky, kx) nesting order as a direct NCHW convolution
   for (int ic = 0; ic < 3; ++ic)
+#pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
       const int iy = y + ky - 1;
+#pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
         const int ix = xg + kx - 1;
-        float v = 0.f;
-        if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[(((size_t)n * 3 + ic) * H + iy) * W + ix];
-        const float* wp = &ws[(cg * 16) * 27 + (ky * 3 + kx) * 3 + ic];
-#pragma unroll
-        for (int o = 0; o < 16; ++o) acc[o] = fmaf(v, wp[o * 27], acc[o]);
+        in[(ky * 3 + kx) * 3 + ic] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[(((size_t)n * 3 + ic) * H + iy) * W + ix] : 0.f;
       }
     }
+  float acc[16];
+  const float* wg = w + (size_t)cg * 16 * 27;                       // [oc][ky][kx][ic], wave-uniform base
+#pragma unroll
+  for (int o = 0; o < 16; ++o) {
+    float a = 0.f;
+    // (ic, ky, kx) order of a direct NCHW convolution
+#pragma unroll
+    for (int ic = 0; ic < 3; ++ic)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) a = fmaf(in[t * 3 + ic], wg[o * 27 + t * 3 + ic], a);
+    acc[o] = a;
+  }
   const size_t pix0 = ((size_t)n * H + y) * W + bx * 64;
   const int npx = min(64, W - bx * 64);
   for (int pass = 0; pass < 2; ++pass) {
@@ -87,15 +96,16 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
       const int oc = cg * 16 + o;
       float v = acc[o];
       if (pass == 1) v = fmaxf(v * scale[oc] + shift[oc], 0.f);
-      tile[px * 64 + oc] = v;
+      tile[px * 68 + oc] = v;
     }
     __syncthreads();
     for (int i = tid; i < 64 * 8; i += 256) {                       // 8-channel vectors
       const int p = i >> 3, c8 = (i & 7) * 8;
       if (p >= npx) continue;
       float v[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = tile[p * 64 + c8 + e];
+      const float4 a0 = *reinterpret_cast<const float4*>(&tile[p * 68 + c8]);
+      const float4 a1 = *reinterpret_cast<const float4*>(&tile[p * 68 + c8 + 4]);
+      v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
       store8<DT>(dst, (pix0 + p) * 64 + c8, v);
     }
   }

@@ -10,6 +10,8 @@ candidates (value + feature row) of every rank are all-gathered and merged, so e
 prototypes the reference would compute over the whole batch.  Hard-pixel sampling (contrast_train.py
 :302-331) is done per rank (documented deviation: the reference samples over the gathered batch).
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -17,6 +19,13 @@ from . import _lib as L
 from .engine import HEAD_LD
 
 _TIE_CACHE = {}
+
+
+def _side_streams(eng, dev):
+    st = getattr(eng, "_side_streams", None)
+    if st is None or st[0].device != dev:
+        st = eng._side_streams = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
+    return st
 
 
 def cpu_tie_pattern(P, k):
@@ -131,17 +140,28 @@ def step(model, img1, img2, label20, bg_threshold=0.20, rng=None, rng_parity=Fal
     world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
     label20 = label20.to(dev).float().contiguous()
     eng.ensure_flat(dev)
+    eng.attach_grads()
+    eng.ensure_packs(dev, L.BF16 if model.precision == "bf16" else L.F32)
+    acc = torch.zeros(8, device=dev, dtype=torch.float32)   # [cls1+cls2, (rvmin1+rvmin2)/2, er_sum, ecr, cross, cross2, intra]
+    # The two views are independent until ER/ECR: run each on its own HIP stream so the small 128x128 view's
+    # launches (which cannot fill 256 CUs) overlap with the 448x448 view's.
+    main = torch.cuda.current_stream(dev)
+    use_streams = os.environ.get("WSEG_STREAMS", "1") != "0"
+    side = _side_streams(eng, dev) if use_streams else (main, main)
+    fork = main.record_event()
     views = []
-    for img in (img1, img2):
-        (cam_low, rvd, _fp, head), S = eng.run_forward(img, save=True, lowres=True)
-        v = _View()
-        v.S, v.h, v.w, v.ctx = img.shape[2], S["h"], S["w"], S
-        v.cam_low, v.rvd, v.head = cam_low, rvd, head
+    for img, st in zip((img1, img2), side):
+        st.wait_event(fork)
+        with torch.cuda.stream(st):
+            (cam_low, rvd, _fp, head), S = eng.run_forward(img, save=True, lowres=True)
+            v = _View()
+            v.S, v.h, v.w, v.ctx = img.shape[2], S["h"], S["w"], S
+            v.cam_low, v.rvd, v.head = cam_low, rvd, head
+            _maps_forward(v, label20, acc, N)
         views.append(v)
     v1, v2 = views
-    acc = torch.zeros(8, device=dev, dtype=torch.float32)   # [cls1+cls2, (rvmin1+rvmin2)/2, er_sum, ecr, cross, cross2, intra]
-    for v in views:
-        _maps_forward(v, label20, acc, N)
+    for st in side:
+        main.wait_stream(st)
     # ---- ER + ECR on the 128x128 maps
     npix = 128 * 128
     er_coef = 1.0 / (N * 20 * npix)
@@ -178,12 +198,17 @@ def step(model, img1, img2, label20, bg_threshold=0.20, rng=None, rng_parity=Fal
         v.dF = _f32(P, 128, dev=dev)
         L.nce_loss_grad(v.fn, v.nrm, v.S_own, v.S_oth, v.y, o.y, v.w_intra, v.protos, o.protos, v.dF, acc[4:7], P,
                         0.1 / (2 * P), 0.05)
-    # ---- into the network
-    for v in (v2, v1):
-        d_head = torch.empty_like(v.head)
-        L.head_grad_fused(v.dF, v.d_cam_low, v.head, d_head, HEAD_LD, N, v.h, v.w, 16, 16)
-        eng.run_backward(v.ctx, None, v.d_rvd, None, None, d_head_rows=d_head)
-        v.ctx = None
+    # ---- into the network (again one stream per view; weight gradients accumulate with atomics)
+    fork = main.record_event()
+    for v, st in zip((v1, v2), side):
+        st.wait_event(fork)
+        with torch.cuda.stream(st):
+            d_head = torch.empty_like(v.head)
+            L.head_grad_fused(v.dF, v.d_cam_low, v.head, d_head, HEAD_LD, N, v.h, v.w, 16, 16)
+            eng.run_backward(v.ctx, None, v.d_rvd, None, None, d_head_rows=d_head)
+            v.ctx = None
+    for st in side:
+        main.wait_stream(st)
     loss_cls = acc[0] * 0.5 + acc[1]
     loss_er = acc[2] * er_coef
     loss_ecr = acc[3]

@@ -23,7 +23,7 @@ def second_view(img1, size=128):
 
 
 class Trainer:
-    def __init__(self, model, optimizer, bg_threshold=0.20, rng=None, rng_parity=False, loss_impl="aten",
+    def __init__(self, model, optimizer, bg_threshold=0.20, rng=None, rng_parity=False, loss_impl="hip",
                  bg_topk_idx=None):
         self.model = model
         self.optimizer = optimizer
