@@ -128,8 +128,16 @@ def main():
         n_launch = max(1, len(prof))
         peak = PEAK_BF16_TFLOPS if a.precision == "bf16" else PEAK_F32_TFLOPS
         achieved = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+        traffic, traffic_src = None, None
+        try:                                                   # HBM bytes per launch from the committed PMC passes
+            import glob                                        # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 on gfx950)
+            f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]
+            traffic = round(json.load(open(f))["conv_igemm"]["hbm_bytes_per_launch"])
+            traffic_src = os.path.relpath(f, ROOT)
+        except Exception:
+            pass
         roof = {"bound": "mfma", "kernel": "conv_igemm_kernel", "achieved": round(achieved, 1), "peak": peak,
-                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "launches_per_step": n_launch // a.steps,
                 "avg_launch_ms": round(tot_ms / n_launch, 4), "avg_launch_gflop": round(tot_fl / n_launch / 1e9, 2),
                 "whole_step_frac": round(conv_flops_model() * a.batch / (ms * 1e-3) / 1e12 / peak, 4)}
