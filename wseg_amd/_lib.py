@@ -221,3 +221,7 @@ def nce_sims(F, p_own, p_oth, fn, nrm, S_own, S_oth, P): _call("wseg_nce_sims", 
 def intra_weights(y, S_own, rkey, rand_flag, w, P): _call("wseg_intra_weights", _v(y), _v(S_own), _v(rkey), _v(rand_flag), _v(w), P)
 def nce_loss_grad(fn, nrm, S_own, S_oth, y_own, y_oth, w_intra, p_own, p_oth, dF, sums, P, coef_cross, coef_intra):
     _call("wseg_nce_loss_grad", _v(fn), _v(nrm), _v(S_own), _v(S_oth), _v(y_own), _v(y_oth), _v(w_intra), _v(p_own), _v(p_oth), _v(dF), _v(sums), P, _f(coef_cross), _f(coef_intra))
+
+
+def gemm256_probe(A, B, Cout, M, N, K, variant=0):
+    check(lib.wseg_gemm256_probe(_v(A), _v(B), _v(Cout), M, N, K, variant, _s()), "wseg_gemm256_probe")

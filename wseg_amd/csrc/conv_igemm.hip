@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const Args a) {
     const int r = wid * 32 + i * 8 + srow;         // row inside the B tile
     lch[i] = pch ^ ((r >> 1) & 7);
     const int oc = n0 + r;
-    if (oc < d.OC) {
+    if (oc < d.OC && d.bm_hint != -2) {                     // (-2: timing diagnostic, B from the zero page)
       bptr[i] = Wp + ((size_t)oc * a.taps * d.IC + (size_t)lch[i] * CH) * ES;
       b_inc[i] = ROWB;
     } else {
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const Args a) {
         if (d.stride == 1) { iy = ty; ix = tx; }
         else { iy = ty / d.stride; ix = tx / d.stride; ok = ok && (iy * d.stride == ty) && (ix * d.stride == tx); }
       }
-      ok = ok && iy >= 0 && iy < d.IH && ix >= 0 && ix < d.IW;
+      ok = ok && iy >= 0 && iy < d.IH && ix >= 0 && ix < d.IW && d.bm_hint != -1;   // (-1: timing diagnostic, A from the zero page)
       if (ok) {
         aptr[i] = IN + ((size_t)(a_img[i] + (long)iy * d.IW + ix) * d.ld_in + (size_t)lcha[i] * CH) * ES;
         a_inc[i] = ROWB;

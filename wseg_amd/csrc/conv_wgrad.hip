@@ -249,29 +249,26 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void conv_wgrad_kernel(const Args 
   }
 }
 
-// ---- 256x256 bf16 ring variant: 32-pixel K-steps, 4 LDS stages (4 x 32 KiB), THREE steps of LDS-DMA in
-// flight behind a counted s_waitcnt vmcnt(N) + raw s_barrier (a __syncthreads() would drain them with
-// vmcnt(0)).  One barrier per step: it publishes stage kt (every wave's DMA pieces of that stage have
-// landed) and retires stage kt-1 (every wave has consumed its reads), which is the stage the next DMA
-// overwrites.  With one workgroup per CU this is what hides the 2-4 us fill latency.
-__global__ __launch_bounds__(512, 2) void conv_wgrad_ring_kernel(const Args a) {
-  constexpr int BO = 256, BI = 256, WC = 4, NW = 8, NT = 512;
-  constexpr int PK = 32, NS = 4;
-  constexpr int ROWB = 512;                        // 256 channels bf16
-  constexpr int TILE = PK * ROWB;                  // 16 KiB per operand
-  constexpr int STAGE = 2 * TILE;
-  constexpr int MI = 8, NJ = 4;
+// ---- 256x256 bf16 phase-pipelined variant (the schedule validated in csrc/gemm256_probe.hip: 1.1-1.2 PF on
+// plain GEMM).  K-tile = 64 pixels; LDS = 2 K-tiles x 4 half-tile slots {dY ch 0-127, dY ch 128-255, X ch 0-127,
+// X ch 128-255}, each [64 pixels][128 ch] = 16 KiB.  A K-tile is 4 phases of 16 MFMAs (one 64(oc) x 32(ic)
+// quadrant of the wave's 128 x 64 tile); each phase refills ONE slot every wave has finished reading:
+//     p1(u): dY0(u+1)   p2(u): dY1(u+1)   p3(u): X0(u+2)   p4(u): X1(u+2)
+// and the only DMA wait is a counted s_waitcnt vmcnt(4) in p4.  One raw s_barrier per phase.  The transposed
+// fragment reads go through inline asm (hipcc would put vmcnt(0) in front of ds_read_tr builtins while
+// LDS-DMA is in flight), with an explicit lgkmcnt(0) + sched_barrier before the MFMAs.
+__global__ __launch_bounds__(512, 2) void conv_wgrad_pipe_kernel(const Args a) {
+  constexpr int BO = 256, BI = 256, NT = 512;
+  constexpr int PK = 64, HALF = 16384, TILE = 4 * HALF, ROWB = 256;
   constexpr int EPI_ROWS = 64, EPI_LD = BI + 4;
-  constexpr int SMEM = NS * STAGE;                 // 128 KiB >= epilogue image (66,560 B)
-  constexpr int PP = TILE / 1024 / NW;             // 2 pieces per wave per operand
-  __shared__ __attribute__((aligned(16))) char smem[SMEM];
+  __shared__ __attribute__((aligned(16))) char smem[2 * TILE];
   const wseg_wgrad_desc& d = a.d;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   int tile, split;
   if ((a.nsplit & 7) == 0) {
-    const int b = blockIdx.x, xcd = b & 7, j = b >> 3, q = a.nsplit >> 3;
-    tile = j % a.ntiles; split = xcd * q + j / a.ntiles;
+    const int b = blockIdx.x, xcd = b & 7, j = b >> 3, q8 = a.nsplit >> 3;
+    tile = j % a.ntiles; split = xcd * q8 + j / a.ntiles;
   } else {
     const int l = xcd_remap(blockIdx.x, a.nwg);
     tile = l % a.ntiles; split = l / a.ntiles;
@@ -288,110 +285,151 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ring_kernel(const Args a) {
   const char* X = reinterpret_cast<const char*>(d.x);
   const char* DY = reinterpret_cast<const char*>(d.dy);
 
-  int rr[PP], lc[PP], cn[PP], cy[PP], cx[PP];
-  bool xok[PP], yok[PP];
+  // staging: thread -> rows r0 = tid>>4 and r0+32 of every half-tile, physical 16-B chunk tid&15
+  const int pch = tid & 15;
+  int rr[2], lc[2];
+  int cn[2], cy[2], cx[2];                          // pixel coordinates of the NEXT X tile to issue
 #pragma unroll
-  for (int i = 0; i < PP; ++i) {
-    const int ci = (wid * PP + i) * 64 + lane;     // physical chunk index in the tile (32 chunks per row)
-    rr[i] = ci >> 5;
-    const int pch = ci & 31, blk = pch >> 1;
-    const int sw = (rr[i] & 3) | (((rr[i] >> 3) & 1) << 2);
-    lc[i] = (((blk & ~7) | ((blk ^ sw) & 7)) << 1) | (pch & 1);
-    xok[i] = (ic0 + lc[i] * 8) < d.IC;
-    yok[i] = (oc0 + lc[i] * 8) < d.OC;
-    const int m = m_begin + rr[i];
+  for (int k = 0; k < 2; ++k) {
+    rr[k] = (tid >> 4) + 32 * k;
+    const int sw = (rr[k] & 3) | (((rr[k] >> 3) & 1) << 2);
+    lc[k] = (((pch >> 1) ^ sw) << 1) | (pch & 1);
+    const int m = m_begin + rr[k];
     const int hw = d.OH * d.OW;
     const int n = m / hw, rem = m - n * hw;
-    cn[i] = n; cy[i] = rem / d.OW; cx[i] = rem - cy[i] * d.OW;
+    cn[k] = n; cy[k] = rem / d.OW; cx[k] = rem - cy[k] * d.OW;
   }
-  auto stage = [&](int buf, int mstep) {
-    char* lo = smem + buf * STAGE;
-    char* li = lo + TILE;
+  const char* xrow[2];                               // source pixel row of the X tile being issued (or nullptr)
+  auto x_prepare = [&](int kt) {                     // call once per X tile, before its two half issues
 #pragma unroll
-    for (int i = 0; i < PP; ++i) {
-      const int m = mstep + rr[i];
-      const char* po = zero + (lane & 15) * 16;
-      const char* pi = po;
+    for (int k = 0; k < 2; ++k) {
+      const int m = m_begin + kt * PK + rr[k];
+      xrow[k] = nullptr;
       if (m < m_end) {
-        if (yok[i]) po = DY + ((size_t)m * d.ld_dy + oc0 + lc[i] * 8) * 2;
-        if (xok[i]) {
-          const int iy = cy[i] * d.stride + ky * d.dil - d.pad;
-          const int ix = cx[i] * d.stride + kx * d.dil - d.pad;
-          if (iy >= 0 && iy < d.IH && ix >= 0 && ix < d.IW)
-            pi = X + ((size_t)((cn[i] * d.IH + iy) * d.IW + ix) * d.ld_x + ic0 + lc[i] * 8) * 2;
-        }
+        const int iy = cy[k] * d.stride + ky * d.dil - d.pad;
+        const int ix = cx[k] * d.stride + kx * d.dil - d.pad;
+        if (iy >= 0 && iy < d.IH && ix >= 0 && ix < d.IW)
+          xrow[k] = X + (size_t)((cn[k] * d.IH + iy) * d.IW + ix) * d.ld_x * 2;
       }
-      glds16(po, lo + (wid * PP + i) * 1024);
-      glds16(pi, li + (wid * PP + i) * 1024);
-      cx[i] += PK;
-      while (cx[i] >= d.OW) { cx[i] -= d.OW; if (++cy[i] == d.OH) { cy[i] = 0; ++cn[i]; } }
+      cx[k] += PK;
+      while (cx[k] >= d.OW) { cx[k] -= d.OW; if (++cy[k] == d.OH) { cy[k] = 0; ++cn[k]; } }
+    }
+  };
+  auto issue_x = [&](int h, int buf) {
+    char* dst = smem + buf * TILE + (2 + h) * HALF + wid * 1024;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int ch = ic0 + h * 128 + lc[k] * 8;
+      const char* p = (xrow[k] && ch < d.IC) ? xrow[k] + (size_t)ch * 2 : zero + (lane & 15) * 16;
+      glds16(p, dst + k * 8192);
+    }
+  };
+  auto issue_y = [&](int h, int buf, int kt) {
+    char* dst = smem + buf * TILE + h * HALF + wid * 1024;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int m = m_begin + kt * PK + rr[k];
+      const int ch = oc0 + h * 128 + lc[k] * 8;
+      const char* p = (m < m_end && ch < d.OC) ? DY + ((size_t)m * d.ld_dy + ch) * 2 : zero + (lane & 15) * 16;
+      glds16(p, dst + k * 8192);
     }
   };
 
-  const int wr = wid / WC, wc = wid % WC;
+  const int wr = wid >> 2, wc = wid & 3;
   const int fcol = lane & 15, fk = lane >> 4;
   const int q = (lane & 15) >> 2, p = lane & 3;
-  f32x4 acc[MI][NJ];
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  // per-lane byte offsets of the transposed reads inside a stage (row h*4+q of k-group fk, swizzled 32-B block)
+  // per-lane byte offsets of the transposed reads inside a half-tile: [ks][h] row, swizzled 32-B block per channel tile
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-  unsigned off_o[2][MI], off_i[2][NJ];
+  unsigned rowoff[2][2], rsw[2][2];
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int row = fk * 8 + h * 4 + q;
-    const int sw = (row & 3) | (((row >> 3) & 1) << 2);
-#pragma unroll
-    for (int i = 0; i < MI; ++i) { const int blk = wr * MI + i; off_o[h][i] = row * ROWB + (((blk & ~7) | ((blk ^ sw) & 7)) << 5) + p * 8; }
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) { const int blk = wc * NJ + j; off_i[h][j] = row * ROWB + (((blk & ~7) | ((blk ^ sw) & 7)) << 5) + p * 8; }
-  }
-  const int nk = (m_end - m_begin + PK - 1) / PK;
-  // prologue: steps 0..2 in flight (4 LDS-DMA instructions per thread per step)
-  stage(0, m_begin);
-  if (nk > 1) stage(1, m_begin + PK);
-  if (nk > 2) stage(2, m_begin + 2 * PK);
-  for (int kt = 0; kt < nk; ++kt) {
-    const int ahead = min(2, nk - 1 - kt);          // steps issued after step kt and still allowed in flight
-    if (ahead == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_barrier" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    if (kt + 3 < nk) stage((kt + 3) & 3, m_begin + (kt + 3) * PK);
-    // transposed fragment reads through inline asm: hipcc's waitcnt pass would otherwise put vmcnt(0) in
-    // front of the first LDS read of every step (it cannot tell the reads from the in-flight LDS-DMA).
-    const unsigned sbase = lds0 + (unsigned)(kt & 3) * STAGE;
-    bf16x4 vo[2][MI], vi[2][NJ];
+  for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(vo[h][i]) : "v"(sbase + off_o[h][i]));
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
-        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(vi[h][j]) : "v"(sbase + TILE + off_i[h][j]));
+      const int row = ks * 32 + fk * 8 + h * 4 + q;
+      rowoff[ks][h] = row * ROWB + p * 8;
+      rsw[ks][h] = (row & 3) | (((row >> 3) & 1) << 2);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    bf16x8 af[MI], bf[NJ];
+
+  f32x4 acc[8][4];
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+  for (int i = 0; i < 8; ++i)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { af[i][e] = vo[0][i][e]; af[i][4 + e] = vo[1][i][e]; }
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { bf[j][e] = vi[0][j][e]; bf[j][4 + e] = vi[1][j][e]; }
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nt = (m_end - m_begin + PK - 1) / PK;
+  // prologue: tile 0 entirely + the X halves of tile 1
+  issue_y(0, 0, 0); issue_y(1, 0, 0);
+  x_prepare(0); issue_x(0, 0); issue_x(1, 0);
+  if (nt > 1) { x_prepare(1); issue_x(0, 1); issue_x(1, 1); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_barrier" ::: "memory");
+
+  bf16x4 va[2][2][4], vb0[2][2][2], vb1[2][2][2];   // [ks][h][tile] raw transposed reads
+  bf16x8 af[2][4], b0[2][2], b1[2][2];
+#define TR(dst, addr) asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(dst) : "v"(addr))
+#define LOAD_A(HA)                                                                                              \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int h = 0; h < 2; ++h)               \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                              \
+      TR(va[ks][h][i], abase + rowoff[ks][h] + ((((HA) * 4 + i) ^ rsw[ks][h]) << 5));
+#define LOAD_B(HB, VB)                                                                                          \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int h = 0; h < 2; ++h)               \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                              \
+      TR(VB[ks][h][j], bbase + rowoff[ks][h] + ((((wc & 1) * 4 + (HB) * 2 + j) ^ rsw[ks][h]) << 5));
+#define PACK_A()                                                                                                \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int i = 0; i < 4; ++i)               \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e) { af[ks][i][e] = va[ks][0][i][e]; af[ks][i][4 + e] = va[ks][1][i][e]; }
+#define PACK_B(BF, VB)                                                                                          \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int j = 0; j < 2; ++j)               \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e) { BF[ks][j][e] = VB[ks][0][j][e]; BF[ks][j][4 + e] = VB[ks][1][j][e]; }
+#define WAIT_LDS() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define MFMA_Q(HA, HB, BF)                                                                                      \
+  do {                                                                                                          \
+    __builtin_amdgcn_s_setprio(1);                                                                              \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int i = 0; i < 4; ++i)             \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                            \
+        acc[(HA) * 4 + i][(HB) * 2 + j] =                                                                       \
+            __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][i], BF[ks][j], acc[(HA) * 4 + i][(HB) * 2 + j], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                              \
+  } while (0)
+
+  for (int u = 0; u < nt; ++u) {
+    const int b = u & 1;
+    const unsigned abase = lds0 + b * TILE + wr * HALF;
+    const unsigned bbase = lds0 + b * TILE + (2 + (wc >> 1)) * HALF;
+    // ---- p1: quadrant (0,0)
+    LOAD_A(0) LOAD_B(0, vb0)
+    if (u + 1 < nt) issue_y(0, b ^ 1, u + 1);
+    WAIT_LDS();
+    PACK_A() PACK_B(b0, vb0)
+    MFMA_Q(0, 0, b0);
+    asm volatile("s_barrier" ::: "memory");
+    // ---- p2: quadrant (0,1)
+    LOAD_B(1, vb1)
+    if (u + 1 < nt) issue_y(1, b ^ 1, u + 1);
+    WAIT_LDS();
+    PACK_B(b1, vb1)
+    MFMA_Q(0, 1, b1);
+    asm volatile("s_barrier" ::: "memory");
+    // ---- p3: quadrant (1,1)
+    LOAD_A(1)
+    if (u + 2 < nt) { x_prepare(u + 2); issue_x(0, b); }
+    WAIT_LDS();
+    PACK_A()
+    MFMA_Q(1, 1, b1);
+    asm volatile("s_barrier" ::: "memory");
+    // ---- p4: quadrant (1,0); counted wait: only X0/X1(u+2) may stay in flight
+    if (u + 2 < nt) { issue_x(1, b); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MFMA_Q(1, 0, b0);
+    asm volatile("s_barrier" ::: "memory");
   }
+#undef TR
+#undef LOAD_A
+#undef LOAD_B
+#undef PACK_A
+#undef PACK_B
+#undef WAIT_LDS
+#undef MFMA_Q
   __syncthreads();
 
   float* img = reinterpret_cast<float*>(smem);
@@ -399,13 +437,13 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ring_kernel(const Args a) {
 #pragma unroll 1
   for (int ps = 0; ps < BO / EPI_ROWS; ++ps) {
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      const int t = wr * MI + i;
+    for (int i = 0; i < 8; ++i) {
+      const int t = wr * 8 + i;
       if (t / 4 == ps) {
         const int row = (t % 4) * 16 + fk * 4;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          const int col = (wc * NJ + j) * 16 + fcol;
+        for (int j = 0; j < 4; ++j) {
+          const int col = (wc * 4 + j) * 16 + fcol;
 #pragma unroll
           for (int e = 0; e < 4; ++e) img[(row + e) * EPI_LD + col] = acc[i][j][e];
         }
@@ -472,9 +510,9 @@ extern "C" int wseg_conv_wgrad(const wseg_wgrad_desc* d, void* stream) {
   a.nwg = a.ntiles * split;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(a.nwg);
-  static const bool use_ring = getenv("WSEG_WGRAD_RING") && getenv("WSEG_WGRAD_RING")[0] == '1';   // opt-in: measured equal to the 2-stage kernel
-  if (big && use_ring)
-    hipLaunchKernelGGL(conv_wgrad_ring_kernel, grid, dim3(512), 0, s, a);
+  static const bool use_pipe = !(getenv("WSEG_WGRAD_PIPE") && getenv("WSEG_WGRAD_PIPE")[0] == '0');
+  if (big && use_pipe)
+    hipLaunchKernelGGL(conv_wgrad_pipe_kernel, grid, dim3(512), 0, s, a);
   else if (big)
     hipLaunchKernelGGL((conv_wgrad_kernel<WSEG_BF16, 256, 256, 2, 4>), grid, dim3(512), 0, s, a);
   else if (d->dtype == WSEG_BF16)
