@@ -132,6 +132,11 @@ int wseg_l2norm_backward(const void* F, int ldf, const float* dFh, const float* 
 int wseg_pcm_forward(const float* Fh, const float* G, float* cam_rv, float* den, int N, int hw, void* stream);
 int wseg_pcm_backward(const float* Fh, const float* G, const float* d_cam_rv, const float* cam_rv, const float* den,
                       float* DN, float* dFh, int N, int hw, void* stream);
+/* bf16-MFMA variants for the bf16 throughput mode (Fb/Gb/DNb = bf16 copies made with wseg_to_bf16) */
+int wseg_to_bf16(const float* in, void* out, long total, void* stream);
+int wseg_pcm_forward_bf16(const void* Fb, const void* Gb, float* cam_rv, float* den, int N, int hw, void* stream);
+int wseg_pcm_backward_bf16(const void* Fb, const void* Gb, const float* d_cam_rv, const float* cam_rv, const float* den,
+                           float* DN, void* DNb, float* dFh, int N, int hw, void* stream);
 
 /* ---- loss step, contrast_train.py:138-395 (forward values + hand-written gradients) -----------
  * All maps planar f32 [N][21][npix]; label20 = float [N][20] multi-hot; loss outputs are device

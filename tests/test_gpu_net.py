@@ -138,3 +138,33 @@ def test_state_dict_roundtrip_and_no_cpu_fallback(nets, proc_sd):
         assert torch.equal(sd2[k].cpu(), proc_sd[k])
     with pytest.raises(RuntimeError):
         m(torch.zeros(1, 3, 32, 32))
+
+
+def test_pcm_bf16_kernels_track_the_exact_f32_kernels():
+    """bf16-MFMA PCM (throughput mode) against the exact-f32 PCM kernels on the same inputs, odd hw (tails)."""
+    from wseg_amd import _lib as L
+    dev = "cuda"
+    g = torch.Generator().manual_seed(0)
+    N, hw = 2, 13 * 9 + 200
+    F = torch.randn(N * hw, 192, generator=g)
+    F[:, :8] += 2.0                                          # correlated features: a realistic mix of positive / negative cosines
+    Fh = (F / (F.norm(dim=1, keepdim=True) + 1e-5)).to(dev)
+    G = torch.rand(N * hw, 32, generator=g)
+    G[:, 21] = 1.0; G[:, 22:] = 0.0
+    G = G.to(dev)
+    d_rv = torch.randn(N, 21, hw, generator=g).to(dev)
+    rv32 = torch.empty(N, 21, hw, device=dev); den32 = torch.empty(N, hw, device=dev)
+    L.pcm_forward(Fh, G, rv32, den32, N, hw)
+    DN = torch.empty(N * hw, 32, device=dev); d32 = torch.zeros(N * hw, 192, device=dev)
+    L.pcm_backward(Fh, G, d_rv, rv32, den32, DN, d32, N, hw)
+    Fb = torch.empty(N * hw, 192, device=dev, dtype=torch.bfloat16); Gb = torch.empty(N * hw, 32, device=dev, dtype=torch.bfloat16)
+    L.to_bf16(Fh, Fb); L.to_bf16(G, Gb)
+    assert torch.equal(Fb, Fh.bfloat16())
+    rv16 = torch.empty_like(rv32); den16 = torch.empty_like(den32)
+    L.pcm_forward_bf16(Fb, Gb, rv16, den16, N, hw)
+    DNb = torch.empty(N * hw, 32, device=dev, dtype=torch.bfloat16); d16 = torch.zeros(N * hw, 192, device=dev)
+    L.pcm_backward_bf16(Fb, Gb, d_rv, rv16, den16, DN, DNb, d16, N, hw)
+    assert _rel(rv16.cpu(), rv32.cpu()) < 2e-2
+    assert _rel(den16.cpu(), den32.cpu()) < 2e-2
+    err = float((d16 - d32).norm() / d32.norm())
+    assert err < 5e-2, err

@@ -225,3 +225,8 @@ def nce_loss_grad(fn, nrm, S_own, S_oth, y_own, y_oth, w_intra, p_own, p_oth, dF
 
 def gemm256_probe(A, B, Cout, M, N, K, variant=0):
     check(lib.wseg_gemm256_probe(_v(A), _v(B), _v(Cout), M, N, K, variant, _s()), "wseg_gemm256_probe")
+
+
+def to_bf16(inp, out): _call("wseg_to_bf16", _v(inp), _v(out), C.c_long(inp.numel()))
+def pcm_forward_bf16(Fb, Gb, cam_rv, den, N, hw): _call("wseg_pcm_forward_bf16", _v(Fb), _v(Gb), _v(cam_rv), _v(den), N, hw)
+def pcm_backward_bf16(Fb, Gb, d_cam_rv, cam_rv, den, DN, DNb, dFh, N, hw): _call("wseg_pcm_backward_bf16", _v(Fb), _v(Gb), _v(d_cam_rv), _v(cam_rv), _v(den), _v(DN), _v(DNb), _v(dFh), N, hw)

@@ -173,6 +173,172 @@ __global__ __launch_bounds__(256, 2) void pcm_kernel(const float* __restrict__ F
   }
 }
 
+
+// ---- bf16-MFMA variant (throughput mode).  Same data flow as pcm_kernel, but every product runs on
+// v_mfma_f32_16x16x32_bf16:
+//   S      : Fb_i . Fb_j over 192 channels = 6 MFMAs per 16x16 sub-tile (A: ds_read_b128 rows, B: registers)
+//   t      : P_i . Q_j over the 32 gate channels = 1 MFMA
+//   acc    : out[j][n] += sum_{i in 32-row tile} W[i,j] V[i][n] = 1 MFMA per 16 columns n; its A operand is built
+//            from BOTH sub-tiles' accumulators with k-slot (g,e) <-> row (e>>2)*16 + 4g + (e&3), so the values a
+//            lane needs are its own; the matching B operand is two ds_read_b64_tr_b16 (rows 4g..4g+3 and 16+4g..).
+// Inputs are bf16 copies (Fb [N][hw][192], P/Q [N][hw][32]); outputs stay f32.
+template <int BWD>
+__global__ __launch_bounds__(256, 2) void pcm_bf16_kernel(const bf16_t* __restrict__ Fb, const bf16_t* __restrict__ Pm,
+                                                          const bf16_t* __restrict__ Qm, float* __restrict__ out0,
+                                                          float* __restrict__ out1, int hw) {
+  constexpr int FR = KF * 2;                  // 384 B per Fb row
+  constexpr int F_T = IT * FR;                // 12288
+  constexpr int P_T = IT * 64;                // 2048 ([32 rows][32 bf16])
+  constexpr int STG = F_T + P_T;              // 14336
+  __shared__ __attribute__((aligned(16))) char smem[2 * STG];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = blockIdx.y;
+  const int j0 = blockIdx.x * 64 + wid * 16;
+  const int col = lane & 15, g = lane >> 4;
+  const char* zero = reinterpret_cast<const char*>(g_wseg_zero_page);
+  const bf16_t* Fn = Fb + (size_t)n * hw * KF;
+  const bf16_t* Pn = Pm + (size_t)n * hw * 32;
+
+  bf16x8 bj[6];                               // Fb[j0+col][32b + 8g + e]
+  {
+    const int jr = min(j0 + col, hw - 1);
+    const bf16x8* src = reinterpret_cast<const bf16x8*>(Fn + (size_t)jr * KF);
+#pragma unroll
+    for (int b = 0; b < 6; ++b) bj[b] = src[b * 4 + g];
+  }
+  bf16x8 qj = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (BWD) {
+    const int jr = min(j0 + col, hw - 1);
+    qj = reinterpret_cast<const bf16x8*>(Qm + ((size_t)n * hw + jr) * 32)[g];
+  }
+
+  // staging: Fb tile 32 rows x 24 chunks = 768 chunks -> 3 per thread (12 pieces); P tile 32 rows x 4 chunks = 128 chunks
+  auto stage = [&](int buf, int i0) {
+    char* lf = smem + buf * STG;
+    char* lp = lf + F_T;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const int piece = wid * 3 + t;
+      const int ci = piece * 64 + lane;
+      const int row = ci / 24, pc = ci - row * 24;
+      const int lc = (pc & ~7) | ((pc ^ (row >> 1)) & 7);
+      const int i = i0 + row;
+      const char* src = (i < hw) ? reinterpret_cast<const char*>(Fn + (size_t)i * KF) + lc * 16 : zero + (lane & 15) * 16;
+      glds16(src, lf + piece * 1024);
+    }
+    if (wid < 2) {                                           // 2 KiB: waves 0,1
+      const int ci = wid * 64 + lane;
+      const int row = ci >> 2, pc = ci & 3;
+      const int i = i0 + row;
+      const char* src = (i < hw) ? reinterpret_cast<const char*>(Pn + (size_t)i * 32) + pc * 16 : zero + (lane & 15) * 16;
+      glds16(src, lp + wid * 1024);
+    }
+  };
+
+  constexpr int NT = BWD ? 12 : 2;
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int q = (lane & 15) >> 2, p = lane & 3;
+
+  const int nti = (hw + IT - 1) / IT;
+  stage(0, 0);
+  __syncthreads();
+  int cur = 0;
+  for (int it = 0; it < nti; ++it) {
+    if (it + 1 < nti) stage(cur ^ 1, (it + 1) * IT);
+    const char* lf = smem + cur * STG;
+    const char* lp = lf + F_T;
+    float wv[2][4];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      const int row = sub * 16 + col;
+      f32x4 sv = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int b = 0; b < 6; ++b) {
+        const int lc = b * 4 + g;
+        const int pc = (lc & ~7) | ((lc ^ (row >> 1)) & 7);
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(lf + row * FR + pc * 16);
+        sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bj[b], sv, 0, 0, 0);
+      }
+      if (!BWD) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wv[sub][r] = fmaxf(sv[r], 0.f);
+      } else {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(lp + row * 64 + g * 16);
+        f32x4 tv = (f32x4){0.f, 0.f, 0.f, 0.f};
+        tv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qj, tv, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wv[sub][r] = sv[r] > 0.f ? tv[r] : 0.f;
+      }
+    }
+    // A operand of the accumulate product: k-slot (g, e) <-> tile row (e>>2)*16 + 4g + (e&3)
+    bf16x8 wa;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) wa[e] = (short)f32_to_bf16(wv[e >> 2][e & 3]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      bf16x8 vb;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int row = h * 16 + 4 * g + q;                  // lane 4q+p of the 16-lane group addresses row q of the 4-row block
+        const char* base;
+        int off;
+        if (!BWD) { base = lp; off = row * 64 + t * 32 + p * 8; }
+        else {
+          const int lc = t * 2 + (p >> 1);
+          const int pc = (lc & ~7) | ((lc ^ (row >> 1)) & 7);
+          base = lf; off = row * FR + pc * 16 + (p & 1) * 8;
+        }
+        const bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 __attribute__((address_space(3)))*)(base + off));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) vb[h * 4 + e] = v[e];
+      }
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, vb, acc[t], 0, 0, 0);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  if (!BWD) {
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const float den = __shfl(acc[1][reg], g * 16 + 5, 64);
+      const int j = j0 + 4 * g + reg;
+      if (j < hw) {
+        out0[((size_t)n * 21 + col) * hw + j] = acc[0][reg] / (den + 1e-5f);
+        if (col < 5) out0[((size_t)n * 21 + 16 + col) * hw + j] = acc[1][reg] / (den + 1e-5f);
+        if (col == 5) out1[(size_t)n * hw + j] = den;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int j = j0 + 4 * g + reg;
+      if (j < hw) {
+        float* dst = out0 + ((size_t)n * hw + j) * KF + col;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) dst[t * 16] += acc[t][reg];
+      }
+    }
+  }
+}
+
+// f32 [rows][cols] -> bf16 copy
+__global__ void to_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, long total) {
+  const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i + 3 < total) {
+    const float4 v = *reinterpret_cast<const float4*>(in + i);
+    uint2 o;
+    o.x = (unsigned)f32_to_bf16(v.x) | ((unsigned)f32_to_bf16(v.y) << 16);
+    o.y = (unsigned)f32_to_bf16(v.z) | ((unsigned)f32_to_bf16(v.w) << 16);
+    *reinterpret_cast<uint2*>(out + i) = o;
+  } else {
+    for (long k = i; k < total; ++k) out[k] = f32_to_bf16(in[k]);
+  }
+}
+
 // Fh = F / (||F|| + 1e-5)   (one wave per pixel row of 192 channels)
 template <int DT>
 __global__ void l2norm_fwd_kernel(const void* __restrict__ F, int ldf, float* __restrict__ Fh, float* __restrict__ nrm, long rows) {
@@ -271,6 +437,35 @@ extern "C" int wseg_l2norm_backward(const void* F, int ldf, const float* dFh, co
   dim3 grid((unsigned)((rows + 3) / 4));
   if (dtype == WSEG_BF16) hipLaunchKernelGGL(l2norm_bwd_kernel<WSEG_BF16>, grid, dim3(256), 0, (hipStream_t)stream, F, ldf, dFh, nrm, dF, lddf, rows);
   else hipLaunchKernelGGL(l2norm_bwd_kernel<WSEG_F32>, grid, dim3(256), 0, (hipStream_t)stream, F, ldf, dFh, nrm, dF, lddf, rows);
+  WSEG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wseg_to_bf16(const float* in, void* out, long total, void* stream) {
+  WSEG_CHECK(in && out && total > 0, "to_bf16: bad arguments");
+  hipLaunchKernelGGL(to_bf16_kernel, dim3((unsigned)((total / 4 + 256) / 256)), dim3(256), 0, (hipStream_t)stream, in, (bf16_t*)out, total);
+  WSEG_LAUNCH_CHECK();
+  return 0;
+}
+
+// bf16-MFMA PCM (throughput mode): Fb / Gb are bf16 copies of Fh [N][hw][192] and G [N][hw][32]
+extern "C" int wseg_pcm_forward_bf16(const void* Fb, const void* Gb, float* cam_rv, float* den, int N, int hw, void* stream) {
+  WSEG_CHECK(Fb && Gb && cam_rv && den && N > 0 && hw > 0, "pcm_forward_bf16: bad arguments");
+  dim3 grid((hw + 63) / 64, N);
+  hipLaunchKernelGGL(pcm_bf16_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)Fb, (const bf16_t*)Gb, (const bf16_t*)nullptr, cam_rv, den, hw);
+  WSEG_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int wseg_pcm_backward_bf16(const void* Fb, const void* Gb, const float* d_cam_rv, const float* cam_rv, const float* den,
+                                      float* DN, void* DNb, float* dFh, int N, int hw, void* stream) {
+  WSEG_CHECK(Fb && Gb && d_cam_rv && cam_rv && den && DN && DNb && dFh && N > 0 && hw > 0, "pcm_backward_bf16: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const long total = (long)N * hw;
+  hipLaunchKernelGGL(pcm_dn_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d_cam_rv, cam_rv, den, DN, hw, total);
+  hipLaunchKernelGGL(to_bf16_kernel, dim3((unsigned)((total * 32 / 4 + 256) / 256)), dim3(256), 0, s, (const float*)DN, (bf16_t*)DNb, total * 32);
+  dim3 grid((hw + 63) / 64, N);
+  hipLaunchKernelGGL(pcm_bf16_kernel<1>, grid, dim3(256), 0, s, (const bf16_t*)Fb, (const bf16_t*)Gb, (const bf16_t*)DNb, dFh, (float*)nullptr, hw);
+  hipLaunchKernelGGL(pcm_bf16_kernel<1>, grid, dim3(256), 0, s, (const bf16_t*)Fb, (const bf16_t*)DNb, (const bf16_t*)Gb, dFh, (float*)nullptr, hw);
   WSEG_LAUNCH_CHECK();
   return 0;
 }

@@ -297,7 +297,15 @@ class Engine:
         L.l2norm_forward(Fm, 192, Fh, nrm, N * hw)
         rvd = torch.empty(N, 21, h, w, device=dev, dtype=torch.float32)
         den = torch.empty(N, hw, device=dev, dtype=torch.float32)
-        L.pcm_forward(Fh, G, rvd, den, N, hw)
+        Fb = Gb = None
+        if dt == L.BF16:                                      # bf16-MFMA PCM (throughput mode); fp32 mode keeps the exact-f32 kernel
+            Fb = torch.empty(N * hw, 192, device=dev, dtype=torch.bfloat16)
+            Gb = torch.empty(N * hw, 32, device=dev, dtype=torch.bfloat16)
+            L.to_bf16(Fh, Fb)
+            L.to_bf16(G, Gb)
+            L.pcm_forward_bf16(Fb, Gb, rvd, den, N, hw)
+        else:
+            L.pcm_forward(Fh, G, rvd, den, N, hw)
         f_proj = head[..., :128].permute(0, 3, 1, 2)
         if lowres:
             outs = (cam_low, rvd, f_proj, head)
@@ -308,7 +316,7 @@ class Engine:
             L.resize_planar_fwd(rvd, cam_rv, N * 21, h, w, H, W, True)
             outs = (cam, cam_rv, f_proj.float() if dt == L.BF16 else f_proj, rvd)
         if save:
-            S.update(fea=fea, head=head, G=G, feat=feat, Fm=Fm, Fh=Fh, nrm=nrm, rvd=rvd.clone(), den=den,
+            S.update(fea=fea, head=head, G=G, feat=feat, Fm=Fm, Fh=Fh, Fb=Fb, Gb=Gb, nrm=nrm, rvd=rvd.clone(), den=den,
                      conv4=conv4, conv5=conv5, h=h, w=w, lowres=lowres)
         return outs, S
 
@@ -356,7 +364,11 @@ class Engine:
         if d_rvd is not None:
             DN = torch.empty(N * hw, 32, device=dev, dtype=torch.float32)
             dFh = torch.zeros(N * hw, 192, device=dev, dtype=torch.float32)
-            L.pcm_backward(S["Fh"], S["G"], d_rvd.contiguous(), S["rvd"], S["den"], DN, dFh, N, hw)
+            if S["Fb"] is not None:
+                DNb = torch.empty(N * hw, 32, device=dev, dtype=torch.bfloat16)
+                L.pcm_backward_bf16(S["Fb"], S["Gb"], d_rvd.contiguous(), S["rvd"], S["den"], DN, DNb, dFh, N, hw)
+            else:
+                L.pcm_backward(S["Fh"], S["G"], d_rvd.contiguous(), S["rvd"], S["den"], DN, dFh, N, hw)
             dF = E(N, h, w, 192)
             L.l2norm_backward(S["Fm"], 192, dFh, S["nrm"], dF, 192, N * hw)
             if trainable("f9"):
