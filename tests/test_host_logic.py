@@ -114,3 +114,30 @@ def test_voc_host_plumbing(tmp_path, lib):
     np.testing.assert_array_equal(imgs[3], np.flip(imgs[2], -1))
     x = norm(np.full((2, 2, 3), 255, np.uint8))
     np.testing.assert_allclose(x[0, 0], [(1 - 0.485) / 0.229, (1 - 0.456) / 0.224, (1 - 0.406) / 0.225], rtol=1e-6)
+
+
+def test_cam_miou_eval(tmp_path, lib):
+    """wseg_amd.eval (counterpart of the reference's eval.py): IoU = TP/(T+P-TP), 255 ignored, npy-dict + bg threshold."""
+    import PIL.Image
+    from wseg_amd import eval as weval
+    gt_dir, pr_dir, npy_dir = tmp_path / "gt", tmp_path / "pred", tmp_path / "cam"
+    for d in (gt_dir, pr_dir, npy_dir):
+        d.mkdir()
+    rng = np.random.default_rng(0)
+    names = ["2007_000001", "2007_000002"]
+    TP = np.zeros(21); P = np.zeros(21); T = np.zeros(21)
+    for n in names:
+        gt = rng.choice([0, 3, 15, 255], size=(20, 30), p=[0.5, 0.2, 0.2, 0.1]).astype(np.uint8)
+        cams = {2: rng.random((20, 30), dtype=np.float32), 14: rng.random((20, 30), dtype=np.float32)}
+        np.save(npy_dir / (n + ".npy"), cams, allow_pickle=True)
+        pred = np.argmax(np.stack([np.full((20, 30), 0.4, np.float32), np.zeros((20, 30), np.float32), np.zeros((20, 30), np.float32),
+                                   cams[2]] + [np.zeros((20, 30), np.float32)] * 11 + [cams[14]] + [np.zeros((20, 30), np.float32)] * 5), 0).astype(np.uint8)
+        PIL.Image.fromarray(gt).save(gt_dir / (n + ".png")); PIL.Image.fromarray(pred).save(pr_dir / (n + ".png"))
+        for c in range(21):                                      # the reference's per-class loop (eval.py:44-52)
+            cal = gt < 255
+            P[c] += np.sum((pred == c) * cal); T[c] += np.sum((gt == c) * cal); TP[c] += np.sum((gt == c) * (pred == gt) * cal)
+    ref_miou = np.mean(TP / (T + P - TP + 1e-10)) * 100
+    a = weval.do_eval(names, str(pr_dir), str(gt_dir), 'png')
+    b = weval.do_eval(names, str(npy_dir), str(gt_dir), 'npy', 0.4)
+    assert abs(a['mIoU'] - ref_miou) < 1e-9 and abs(b['mIoU'] - ref_miou) < 1e-9
+    assert a['bird'] > 0 and a['person'] > 0 and a['aeroplane'] == 0

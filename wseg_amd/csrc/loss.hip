@@ -490,29 +490,62 @@ __global__ __launch_bounds__(128) void proto_merge_kernel(const float* __restric
   protos[c * 128 + tid] = pr / fmaxf(sqrtf(ss), 1e-12f);
 }
 
-// ---- fn = F/max(||F||,1e-12); S_own = fn.protos_own^T ; S_oth = fn.protos_oth^T    (one wave per pixel)
+// ---- fn = F/max(||F||,1e-12); S_own = fn.protos_own^T ; S_oth = fn.protos_oth^T  on exact-f32 MFMA.
+// One wave = 16 pixels at a time: [16 px] x [48 = 21 own | 21 other | 6 pad classes] x K=128 as 3 x 32
+// v_mfma_f32_16x16x4_f32.  Lane (row = lane&15, g = lane>>4) loads F[row][16b + 4g .. +3] (8 x 16 B), which is
+// both its A fragment (k-slot g <-> channel 16b+4g+e in MFMA (b,e)) and the piece of fn it writes back; the row
+// norm is two xor-shuffles across g.  The prototypes live in registers in the matching B layout.
 __global__ __launch_bounds__(256) void nce_sims_kernel(const float* __restrict__ F, const float* __restrict__ p_own, const float* __restrict__ p_oth,
                                                        float* __restrict__ fn, float* __restrict__ nrm, float* __restrict__ S_own, float* __restrict__ S_oth, int P) {
-  __shared__ float po[21 * 128], pt[21 * 128];
-  for (int i = threadIdx.x; i < 21 * 128; i += 256) { po[i] = p_own[i]; pt[i] = p_oth[i]; }
-  __syncthreads();
-  const int lane = threadIdx.x & 63;
-  for (int p = blockIdx.x * 4 + (threadIdx.x >> 6); p < P; p += gridDim.x * 4) {
-    const float a = F[(size_t)p * 128 + lane], b = F[(size_t)p * 128 + 64 + lane];
-    float ss = a * a + b * b;
+  const int lane = threadIdx.x & 63, col = lane & 15, g = lane >> 4;
+  f32x4 pb[3][8];                                            // B operand: class cc = t*16+col, channels 16b+4g..
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+  for (int t = 0; t < 3; ++t) {
+    const int cc = t * 16 + col;
+    const float* src = cc < 21 ? p_own + cc * 128 : (cc < 42 ? p_oth + (cc - 21) * 128 : nullptr);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) pb[t][b] = src ? *reinterpret_cast<const f32x4*>(src + b * 16 + 4 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  const int ngrp = (P + 15) >> 4;
+  for (int grp = blockIdx.x * 4 + (threadIdx.x >> 6); grp < ngrp; grp += gridDim.x * 4) {
+    const int row = grp * 16 + col;
+    const bool ok = row < P;
+    const float* fr = F + (size_t)min(row, P - 1) * 128 + 4 * g;
+    f32x4 a[8];
+    float ss = 0.f;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) { a[b] = *reinterpret_cast<const f32x4*>(fr + b * 16); ss += a[b][0] * a[b][0] + a[b][1] * a[b][1] + a[b][2] * a[b][2] + a[b][3] * a[b][3]; }
+    ss += __shfl_xor(ss, 16, 64); ss += __shfl_xor(ss, 32, 64);
     const float nr = sqrtf(ss);
     const float inv = 1.f / fmaxf(nr, 1e-12f);
-    const float fa = a * inv, fb = b * inv;
-    fn[(size_t)p * 128 + lane] = fa; fn[(size_t)p * 128 + 64 + lane] = fb;
-    if (lane == 0) nrm[p] = nr;
-    for (int c = 0; c < 21; ++c) {
-      float d1 = fa * po[c * 128 + lane] + fb * po[c * 128 + 64 + lane];
-      float d2 = fa * pt[c * 128 + lane] + fb * pt[c * 128 + 64 + lane];
+    if (ok) {
+      float* fo = fn + (size_t)row * 128 + 4 * g;
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) { d1 += __shfl_xor(d1, o, 64); d2 += __shfl_xor(d2, o, 64); }
-      if (lane == 0) { S_own[(size_t)p * 21 + c] = d1; S_oth[(size_t)p * 21 + c] = d2; }
+      for (int b = 0; b < 8; ++b) *reinterpret_cast<f32x4*>(fo + b * 16) = a[b] * inv;
+      if (g == 0) nrm[row] = nr;
+    }
+    f32x4 acc[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < 8; ++b)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[b][e], pb[t][b][e], acc[t], 0, 0, 0);
+    // acc[t][r] = F[row 4g+r] . P[class t*16+col]; scale by that row's 1/norm (held by lane 4g+r)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float ir = __shfl(inv, 4 * g + r, 64);
+      const int prow = grp * 16 + 4 * g + r;
+      if (prow < P) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          const int cc = t * 16 + col;
+          if (cc < 21) S_own[(size_t)prow * 21 + cc] = acc[t][r] * ir;
+          else if (cc < 42) S_oth[(size_t)prow * 21 + cc - 21] = acc[t][r] * ir;
+        }
+      }
     }
   }
 }
@@ -573,71 +606,112 @@ __global__ __launch_bounds__(1024) void intra_weights_kernel(const int* __restri
   }
 }
 
-// ---- per-pixel NCE losses + gradient w.r.t. the un-normalised features F (contrast_train.py:261-334)
-//   lane c < 21 owns class c.  sums[0..2] += cross, cross2, intra (already weighted by their means)
+// ---- per-pixel NCE losses + gradient w.r.t. the un-normalised features F (contrast_train.py:261-334).
+// One wave = 64 pixels.  Phase A, one lane per pixel: the 21+21 similarities in registers -> the three InfoNCE
+// terms and d(loss)/d(similarity) (44 values, written to the wave's LDS slab).  Phase B, exact-f32 MFMA:
+//   d fn[ch][px] = sum_class [P_own|P_oth]^T[ch][class] * dS[class][px]      (8 channel tiles x 11 x 16x16x4 per 16 px)
+// whose C layout gives every lane 4 consecutive channels of one pixel: fn is loaded and dF stored 16 B per lane;
+// the F.normalize backward needs one dot product per pixel = two xor-shuffles across the lane groups.
 __global__ __launch_bounds__(256) void nce_loss_grad_kernel(const float* __restrict__ fn, const float* __restrict__ nrm, const float* __restrict__ S_own,
                                                             const float* __restrict__ S_oth, const int* __restrict__ y_own, const int* __restrict__ y_oth,
                                                             const float* __restrict__ w_intra, const float* __restrict__ p_own, const float* __restrict__ p_oth,
                                                             float* __restrict__ dF, float* __restrict__ sums, int P, float coef_cross, float coef_intra) {
-  __shared__ float po[21 * 128], pt[21 * 128];
+  __shared__ float dS[4][64][45];                            // [wave][pixel][class 0..43] (+1 pad)
   __shared__ float red[3][4];
-  for (int i = threadIdx.x; i < 21 * 128; i += 256) { po[i] = p_own[i]; pt[i] = p_oth[i]; }
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, col = lane & 15, g = lane >> 4;
   const float itau = 10.f;                                   // 1 / 0.1
+  // A operand of phase B: [P_own|P_oth]^T[ch = mt*16+col][class 4kk+g], kk = 0..10
+  float pa[8][11];
+#pragma unroll
+  for (int kk = 0; kk < 11; ++kk) {
+    const int cc = 4 * kk + g;
+    const float* src = cc < 21 ? p_own + cc * 128 : (cc < 42 ? p_oth + (cc - 21) * 128 : nullptr);
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) pa[mt][kk] = src ? src[mt * 16 + col] : 0.f;
+  }
   float l_cross = 0.f, l_cross2 = 0.f, l_intra = 0.f;
-  for (int p = blockIdx.x * 4 + wv; p < P; p += gridDim.x * 4) {
-    const int yo = y_own[p], yt = y_oth[p];
-    const float so = lane < 21 ? S_own[(size_t)p * 21 + lane] : -INFINITY;
-    const float st = lane < 21 ? S_oth[(size_t)p * 21 + lane] : -INFINITY;
-    const float eo = lane < 21 ? expf(so * itau) : 0.f;
-    const float et = lane < 21 ? expf(st * itau) : 0.f;
-    float sum_o = eo, sum_t = et;
+  const int ngrp = (P + 63) >> 6;
+  for (int grp = blockIdx.x * 4 + wv; grp < ngrp; grp += gridDim.x * 4) {
+    // ---------------- phase A: lane = pixel
+    {
+      const int p = grp * 64 + lane;
+      const bool ok = p < P;
+      const int pc = min(p, P - 1);
+      float so[21], st[21];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { sum_o += __shfl_xor(sum_o, o, 64); sum_t += __shfl_xor(sum_t, o, 64); }
-    // 1.1 cross-prototype: other view's prototypes, own label;  1.2 cross-pseudo-label: own prototypes, other label
-    const float a_cross = __shfl(et, yo, 64), a_cross2 = __shfl(eo, yt, 64);
-    // 2. intra: own prototypes, own label, negatives = similarity ranks 3..12 (descending, lower index first on ties)
-    int rank = 0;
-    for (int c = 0; c < 21; ++c) { const float sc = __shfl(so, c, 64); if (sc > so || (sc == so && c < lane)) ++rank; }
-    const bool is_neg = lane < 21 && rank >= 3 && rank <= 12;
-    const float a1 = __shfl(eo, yo, 64);
-    float a2 = is_neg ? eo : 0.f;
+      for (int c = 0; c < 21; ++c) { so[c] = S_own[(size_t)pc * 21 + c]; st[c] = S_oth[(size_t)pc * 21 + c]; }
+      const int yo = y_own[pc], yt = y_oth[pc];
+      const float wi = ok ? w_intra[pc] : 0.f;
+      float eo[21], et[21], sum_o = 0.f, sum_t = 0.f, s_yo = 0.f, e_yo_t = 0.f, e_yt_o = 0.f, e_yo_o = 0.f;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) a2 += __shfl_xor(a2, o, 64);
-    a2 += a1;
-    const float wi = w_intra[p];
-    if (lane == 0) {
-      l_cross += -logf(a_cross / sum_t) * coef_cross;
-      l_cross2 += -logf(a_cross2 / sum_o) * coef_cross;
-      if (wi != 0.f) l_intra += -logf(a1 / a2) * wi * coef_intra;
+      for (int c = 0; c < 21; ++c) {
+        eo[c] = expf(so[c] * itau); et[c] = expf(st[c] * itau);
+        sum_o += eo[c]; sum_t += et[c];
+        if (c == yo) { s_yo = so[c]; e_yo_t = et[c]; e_yo_o = eo[c]; }
+        if (c == yt) e_yt_o = eo[c];
+      }
+      // semi-hard negatives: similarity ranks 3..12 (descending, lower index first on ties)
+      float a2 = e_yo_o;
+      unsigned negmask = 0;
+#pragma unroll
+      for (int c = 0; c < 21; ++c) {
+        int rank = 0;
+#pragma unroll
+        for (int c2 = 0; c2 < 21; ++c2) rank += (so[c2] > so[c] || (so[c2] == so[c] && c2 < c)) ? 1 : 0;
+        if (rank >= 3 && rank <= 12) { negmask |= 1u << c; a2 += eo[c]; }
+      }
+      if (ok) {
+        l_cross += -logf(e_yo_t / sum_t) * coef_cross;       // 1.1 cross-prototype: other view's prototypes, own label
+        l_cross2 += -logf(e_yt_o / sum_o) * coef_cross;      // 1.2 cross-pseudo-label: own prototypes, other label
+        if (wi != 0.f) l_intra += -logf(e_yo_o / a2) * wi * coef_intra;
+      }
+      (void)s_yo;
+      const float kc = ok ? coef_cross * itau : 0.f, ki = coef_intra * wi * itau;
+#pragma unroll
+      for (int c = 0; c < 21; ++c) {
+        float go = kc * (eo[c] / sum_o - (c == yt ? 1.f : 0.f));
+        if (wi != 0.f) go += ki * (((c == yo ? 1.f : 0.f) + ((negmask >> c) & 1u)) * eo[c] / a2 - (c == yo ? 1.f : 0.f));
+        dS[wv][lane][c] = go;
+        dS[wv][lane][21 + c] = kc * (et[c] / sum_t - (c == yo ? 1.f : 0.f));
+      }
+      dS[wv][lane][42] = 0.f; dS[wv][lane][43] = 0.f;
     }
-    // gradients w.r.t. the similarities
-    float g_t = 0.f, g_o = 0.f;
-    if (lane < 21) {
-      g_t = coef_cross * itau * (et / sum_t - (lane == yo ? 1.f : 0.f));
-      g_o = coef_cross * itau * (eo / sum_o - (lane == yt ? 1.f : 0.f));
-      if (wi != 0.f) {
-        const float mult = (lane == yo ? 1.f : 0.f) + (is_neg ? 1.f : 0.f);
-        g_o += coef_intra * wi * itau * (mult * eo / a2 - (lane == yo ? 1.f : 0.f));
+    __builtin_amdgcn_wave_barrier();
+    // ---------------- phase B: 4 sub-groups of 16 pixels
+#pragma unroll 1
+    for (int sub = 0; sub < 4; ++sub) {
+      const int p = grp * 64 + sub * 16 + col;               // B/C column = pixel
+      f32x4 acc[8];
+#pragma unroll
+      for (int mt = 0; mt < 8; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 11; ++kk) {
+        const float bv = dS[wv][sub * 16 + col][4 * kk + g];
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[mt][kk], bv, acc[mt], 0, 0, 0);
+      }
+      // acc[mt][r] = d fn[p][ch = mt*16 + 4g + r]
+      const int pc = min(p, P - 1);
+      f32x4 f[8];
+      float dot = 0.f;
+#pragma unroll
+      for (int mt = 0; mt < 8; ++mt) {
+        f[mt] = *reinterpret_cast<const f32x4*>(fn + (size_t)pc * 128 + mt * 16 + 4 * g);
+        dot += acc[mt][0] * f[mt][0] + acc[mt][1] * f[mt][1] + acc[mt][2] * f[mt][2] + acc[mt][3] * f[mt][3];
+      }
+      dot += __shfl_xor(dot, 16, 64); dot += __shfl_xor(dot, 32, 64);
+      const float nr = nrm[pc];
+      const float inv = nr > 1e-12f ? 1.f / nr : 0.f;        // below eps F.normalize divides by a constant: treat as dead
+      if (p < P) {
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt)
+          *reinterpret_cast<f32x4*>(dF + (size_t)p * 128 + mt * 16 + 4 * g) = (acc[mt] - f[mt] * dot) * inv;
       }
     }
-    // d fn = sum_c g_o[c] P_own[c] + g_t[c] P_oth[c]   (lane owns channels lane, lane+64)
-    float da = 0.f, db = 0.f;
-    for (int c = 0; c < 21; ++c) {
-      const float go = __shfl(g_o, c, 64), gt = __shfl(g_t, c, 64);
-      da += go * po[c * 128 + lane] + gt * pt[c * 128 + lane];
-      db += go * po[c * 128 + 64 + lane] + gt * pt[c * 128 + 64 + lane];
-    }
-    const float fa = fn[(size_t)p * 128 + lane], fb = fn[(size_t)p * 128 + 64 + lane];
-    float dot = da * fa + db * fb;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
-    const float nr = nrm[p];
-    const float inv = nr > 1e-12f ? 1.f / nr : 0.f;          // below eps F.normalize divides by a constant: treat as dead
-    dF[(size_t)p * 128 + lane] = (da - fa * dot) * inv;
-    dF[(size_t)p * 128 + 64 + lane] = (db - fb * dot) * inv;
+    __builtin_amdgcn_wave_barrier();
   }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { l_cross += __shfl_xor(l_cross, o, 64); l_cross2 += __shfl_xor(l_cross2, o, 64); l_intra += __shfl_xor(l_intra, o, 64); }
   if (lane == 0) { red[0][wv] = l_cross; red[1][wv] = l_cross2; red[2][wv] = l_intra; }
   __syncthreads();
   if (threadIdx.x < 3) {
@@ -781,7 +855,7 @@ extern "C" int wseg_proto_merge(const float* cand_val, const float* cand_feat, c
 
 extern "C" int wseg_nce_sims(const float* F, const float* p_own, const float* p_oth, float* fn, float* nrm, float* S_own, float* S_oth, int P, void* stream) {
   WSEG_CHECK(F && p_own && p_oth && fn && nrm && S_own && S_oth && P > 0, "nce_sims: bad arguments");
-  hipLaunchKernelGGL(nce_sims_kernel, dim3(std::min(1024, (P + 3) / 4)), dim3(256), 0, ST, F, p_own, p_oth, fn, nrm, S_own, S_oth, P);
+  hipLaunchKernelGGL(nce_sims_kernel, dim3(std::min(2048, (P + 63) / 64)), dim3(256), 0, ST, F, p_own, p_oth, fn, nrm, S_own, S_oth, P);
   WSEG_LAUNCH_CHECK();
   return 0;
 }
@@ -796,7 +870,7 @@ extern "C" int wseg_nce_loss_grad(const float* fn, const float* nrm, const float
                                   const float* w_intra, const float* p_own, const float* p_oth, float* dF, float* sums, int P,
                                   float coef_cross, float coef_intra, void* stream) {
   WSEG_CHECK(fn && nrm && S_own && S_oth && y_own && y_oth && w_intra && p_own && p_oth && dF && sums && P > 0, "nce_loss_grad: bad arguments");
-  hipLaunchKernelGGL(nce_loss_grad_kernel, dim3(std::min(1024, (P + 3) / 4)), dim3(256), 0, ST, fn, nrm, S_own, S_oth, y_own, y_oth, w_intra, p_own, p_oth,
+  hipLaunchKernelGGL(nce_loss_grad_kernel, dim3(std::min(2048, (P + 255) / 256)), dim3(256), 0, ST, fn, nrm, S_own, S_oth, y_own, y_oth, w_intra, p_own, p_oth,
                      dF, sums, P, coef_cross, coef_intra);
   WSEG_LAUNCH_CHECK();
   return 0;
