@@ -139,3 +139,22 @@ def test_stem(dt):
     tol = dict(rtol=1e-5, atol=1e-5) if dt == "f32" else dict(rtol=1e-2, atol=2e-2)
     np.testing.assert_allclose(raw_g.float().cpu().numpy(), _nhwc(y).numpy(), **tol)
     np.testing.assert_allclose(act_g.float().cpu().numpy(), _nhwc(act).numpy(), **tol)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_conv_many_row_tiles(dt):
+    """521 row tiles (more than the 512 resident workgroups), odd image size, residual epilogue."""
+    from wseg_amd import _lib as L
+    tdt = torch.float32 if dt == "f32" else torch.bfloat16
+    N, H, W, IC, OC = 1, 258, 258, 64, 128
+    x = _rand((N, IC, H, W), 1).to(tdt).float()
+    w = _rand((OC, IC, 3, 3), 2, 0.05).to(tdt).float()
+    res = _rand((N, OC, H, W), 3).to(tdt).float()
+    y = F.conv2d(x, w, None, 1, 1, 1) + res
+    dev = "cuda"
+    yg = torch.empty(N, H, W, OC, device=dev, dtype=tdt)
+    wf = w.permute(0, 2, 3, 1).reshape(OC, 9, IC).contiguous().to(dev, tdt)
+    L.conv_igemm(_nhwc(x).to(dev, tdt), wf, yg, N=N, IH=H, IW=W, IC=IC, OH=H, OW=W, OC=OC, KH=3, KW=3, pad=1,
+                 r_post=_nhwc(res).to(dev, tdt))
+    tol = dict(rtol=2e-5, atol=2e-5) if dt == "f32" else dict(rtol=2e-2, atol=2e-2)
+    np.testing.assert_allclose(yg.float().cpu().numpy(), _nhwc(y).numpy(), **tol)

@@ -25,6 +25,7 @@ struct Args {
   int cpt;          // K-steps per tap = IC*ES/128
   int ntn;          // column tiles
   int nwg;
+  int row0;         // first output row (pixel) of this launch (a launch may cover a row sub-range)
 };
 
 // BM = 128 (default) or 64 (few output pixels: twice the workgroups for the same work)
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const Args a) {
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tile = xcd_remap(blockIdx.x, a.nwg);
   const int tm = tile / a.ntn, tn = tile - tm * a.ntn;
-  const int m0 = tm * BM, n0 = tn * BN;
+  const int m0 = a.row0 + tm * BM, n0 = tn * BN;
 
   const char* zero = reinterpret_cast<const char*>(g_wseg_zero_page);
   const char* IN = reinterpret_cast<const char*>(d.in);
@@ -325,21 +326,28 @@ extern "C" int wseg_conv_igemm(const wseg_conv_desc* d, void* stream) {
   a.ntn = (d->OC + BN - 1) / BN;
   // few output pixels (view 2, 16x16 maps): 64-row tiles double the workgroup count
   const bool small = d->bm_hint == 64 || (d->bm_hint != 128 && ((M + 127) / 128) * a.ntn < 384 && M > 64);
-  const int bm = small ? 64 : 128;
-  const long ntm = (M + bm - 1) / bm;
-  a.nwg = (int)(ntm * a.ntn);
   hipStream_t s = (hipStream_t)stream;
   WSEG_CHECK(d->out || d->epi == 0, "conv_igemm: epilogue %d needs `out`", d->epi);
-#define WSEG_LAUNCH_CONV(DT_, EPI_)                                                                           \
-  do {                                                                                                        \
-    if (small) hipLaunchKernelGGL((conv_igemm_kernel<DT_, EPI_, 64>), dim3(a.nwg), dim3(256), 0, s, a);       \
-    else hipLaunchKernelGGL((conv_igemm_kernel<DT_, EPI_, 128>), dim3(a.nwg), dim3(256), 0, s, a);            \
+#define WSEG_LAUNCH_CONV1(DT_, EPI_, BM_) hipLaunchKernelGGL((conv_igemm_kernel<DT_, EPI_, BM_>), dim3(a.nwg), dim3(256), 0, s, a)
+#define WSEG_LAUNCH_CONV(BM_)                                                                                   \
+  do {                                                                                                          \
+    if (d->dtype == WSEG_BF16) {                                                                                \
+      if (d->epi == 0) WSEG_LAUNCH_CONV1(WSEG_BF16, 0, BM_); else if (d->epi == 1) WSEG_LAUNCH_CONV1(WSEG_BF16, 1, BM_); else WSEG_LAUNCH_CONV1(WSEG_BF16, 2, BM_); \
+    } else {                                                                                                    \
+      if (d->epi == 0) WSEG_LAUNCH_CONV1(WSEG_F32, 0, BM_); else if (d->epi == 1) WSEG_LAUNCH_CONV1(WSEG_F32, 1, BM_); else WSEG_LAUNCH_CONV1(WSEG_F32, 2, BM_); \
+    }                                                                                                           \
   } while (0)
-  if (d->dtype == WSEG_BF16) {
-    if (d->epi == 0) WSEG_LAUNCH_CONV(WSEG_BF16, 0); else if (d->epi == 1) WSEG_LAUNCH_CONV(WSEG_BF16, 1); else WSEG_LAUNCH_CONV(WSEG_BF16, 2);
+  a.row0 = 0;
+  if (small) {
+    a.nwg = (int)(((M + 63) / 64) * a.ntn);
+    WSEG_LAUNCH_CONV(64);
   } else {
-    if (d->epi == 0) WSEG_LAUNCH_CONV(WSEG_F32, 0); else if (d->epi == 1) WSEG_LAUNCH_CONV(WSEG_F32, 1); else WSEG_LAUNCH_CONV(WSEG_F32, 2);
+    // (A split into full rounds of 128-row tiles + a short launch of 64-row tiles for the remainder was measured:
+    //  no gain — workgroups are back-filled as they finish, rounds are not discrete — so one launch it is.)
+    a.nwg = (int)(((M + 127) / 128) * a.ntn);
+    WSEG_LAUNCH_CONV(128);
   }
+#undef WSEG_LAUNCH_CONV1
 #undef WSEG_LAUNCH_CONV
   WSEG_LAUNCH_CHECK();
   return 0;
