@@ -61,6 +61,10 @@ typedef struct wseg_conv_desc {
   int32_t relu_out2;   /* 1: out2 gets the ReLU (default); 0: affine only */
   int32_t relu_lt;     /* epi 0: ReLU on `out` channels < relu_lt (fused head: f_proj | cam); 0 = none */
   int32_t bm_hint;     /* 0 = library chooses the pixel-tile height (64 for few pixels, else 128); 64 / 128 = force */
+  /* optional SECOND row segment (the 128x128 view batched behind the 448x448 view in one launch): rows
+   * [0, N*OH*OW) use (IH,IW,OH,OW); rows beyond use (IH2,IW2,OH2,OW2), same N, their input pixels follow the
+   * first segment's N*IH*IW rows; drop then has 2N rows.  OH2 == 0: single segment. */
+  int32_t IH2, IW2, OH2, OW2;
 } wseg_conv_desc;
 int wseg_conv_igemm(const wseg_conv_desc* d, void* stream);
 
@@ -78,6 +82,7 @@ typedef struct wseg_wgrad_desc {
   int32_t dtype, split_k;      /* split_k <= 0: library heuristic */
   int32_t IC_dw, OC_dw;        /* real extents of dw ([OC_dw][KH*KW][IC_dw]); IC/OC may be padded */
   int32_t tile_hint;           /* 0 = library chooses (256x256 tiles for bf16 with OC,IC >= 256), 128 = force 128x128 */
+  int32_t IH2, IW2, OH2, OW2;  /* optional second row segment, as in wseg_conv_desc (OH2 == 0: none) */
 } wseg_wgrad_desc;
 int wseg_conv_wgrad(const wseg_wgrad_desc* d, void* stream);
 

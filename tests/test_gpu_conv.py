@@ -158,3 +158,44 @@ def test_conv_many_row_tiles(dt):
                  r_post=_nhwc(res).to(dev, tdt))
     tol = dict(rtol=2e-5, atol=2e-5) if dt == "f32" else dict(rtol=2e-2, atol=2e-2)
     np.testing.assert_allclose(yg.float().cpu().numpy(), _nhwc(y).numpy(), **tol)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("geom", [(3, 1, 2), (3, 2, 1), (1, 2, 1)])
+def test_conv_two_row_segments(dt, geom):
+    """Two views batched in one launch: rows [0,N*OH*OW) use geometry 1, the rest geometry 2 (fwd, dgrad, wgrad)."""
+    from wseg_amd import _lib as L
+    k, s, d = geom
+    tdt = torch.float32 if dt == "f32" else torch.bfloat16
+    N, IC, OC = 2, 64, 256
+    (H1, W1), (H2, W2) = (20, 18), (9, 11)
+    pad = d * (k // 2)
+    osz = lambda h: (h + 2 * pad - d * (k - 1) - 1) // s + 1
+    xs = [_rand((N, IC, H1, W1), 1).to(tdt).float().requires_grad_(True), _rand((N, IC, H2, W2), 2).to(tdt).float().requires_grad_(True)]
+    w = _rand((OC, IC, k, k), 3, (2.0 / (IC * k * k)) ** 0.5).to(tdt).float().requires_grad_(True)
+    ys = [F.conv2d(x, w, None, s, pad, d) for x in xs]
+    dys = [_rand(tuple(y.shape), 4 + i).to(tdt).float() for i, y in enumerate(ys)]
+    sum((y * dy).sum() for y, dy in zip(ys, dys)).backward()
+    dev = "cuda"
+    rows = lambda t: _nhwc(t).reshape(-1, t.shape[1])
+    xj = torch.cat([rows(x.detach()) for x in xs]).to(dev, tdt)
+    dyj = torch.cat([rows(dy) for dy in dys]).to(dev, tdt)
+    wm = w.detach().permute(0, 2, 3, 1).contiguous().to(dev)
+    wf = torch.empty(OC, k * k, IC, device=dev, dtype=tdt); wt = torch.empty(IC, k * k, OC, device=dev, dtype=tdt)
+    L.pack_weights(wm, wf, wt, OC, k * k, IC, OC, IC, L.dtype_code(wf))
+    O1, O2 = (osz(H1), osz(W1)), (osz(H2), osz(W2))
+    seg_f = (H2, W2, O2[0], O2[1])
+    yg = torch.empty(dyj.shape[0], OC, device=dev, dtype=tdt)
+    L.conv_igemm(xj, wf, yg, N=N, IH=H1, IW=W1, IC=IC, OH=O1[0], OW=O1[1], OC=OC, KH=k, KW=k, stride=s, dil=d, pad=pad, seg2=seg_f)
+    tol = dict(rtol=2e-5, atol=2e-5) if dt == "f32" else dict(rtol=2e-2, atol=2e-2)
+    np.testing.assert_allclose(yg.float().cpu().numpy(), torch.cat([rows(y.detach()) for y in ys]).numpy(), **tol)
+    dxg = torch.empty(xj.shape[0], IC, device=dev, dtype=tdt)
+    L.conv_igemm(dyj, wt, dxg, N=N, IH=O1[0], IW=O1[1], IC=OC, OH=H1, OW=W1, OC=IC, KH=k, KW=k, stride=s, dil=d, pad=pad, mode=1,
+                 seg2=(O2[0], O2[1], H2, W2))
+    np.testing.assert_allclose(dxg.float().cpu().numpy(), torch.cat([rows(x.grad) for x in xs]).numpy(), **tol)
+    ref = w.grad.permute(0, 2, 3, 1).reshape(OC, k * k, IC).numpy()
+    for hint in (128, 256):
+        dwg = torch.zeros(OC, k * k, IC, device=dev, dtype=torch.float32)
+        L.conv_wgrad(xj, dyj, dwg, N=N, IH=H1, IW=W1, IC=IC, OH=O1[0], OW=O1[1], OC=OC, KH=k, KW=k, stride=s, dil=d, pad=pad,
+                     seg2=seg_f, tile_hint=hint, split_k=2)
+        assert np.abs(dwg.cpu().numpy() - ref).max() / np.abs(ref).max() < (2e-5 if dt == "f32" else 1e-2)

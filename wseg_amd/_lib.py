@@ -26,7 +26,8 @@ class ConvDesc(C.Structure):
                 ("ld_rpre", C.c_int32), ("ld_rpost", C.c_int32), ("ld_mask", C.c_int32),
                 ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("dil", C.c_int32), ("pad", C.c_int32),
                 ("mode", C.c_int32), ("epi", C.c_int32), ("dtype", C.c_int32), ("relu_out2", C.c_int32),
-                ("relu_lt", C.c_int32), ("bm_hint", C.c_int32)]
+                ("relu_lt", C.c_int32), ("bm_hint", C.c_int32),
+                ("IH2", C.c_int32), ("IW2", C.c_int32), ("OH2", C.c_int32), ("OW2", C.c_int32)]
 
 
 class WgradDesc(C.Structure):
@@ -35,7 +36,8 @@ class WgradDesc(C.Structure):
                 ("OH", C.c_int32), ("OW", C.c_int32), ("OC", C.c_int32), ("ld_dy", C.c_int32),
                 ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("dil", C.c_int32), ("pad", C.c_int32),
                 ("dtype", C.c_int32), ("split_k", C.c_int32), ("IC_dw", C.c_int32), ("OC_dw", C.c_int32),
-                ("tile_hint", C.c_int32)]
+                ("tile_hint", C.c_int32),
+                ("IH2", C.c_int32), ("IW2", C.c_int32), ("OH2", C.c_int32), ("OW2", C.c_int32)]
 
 
 def _load():
@@ -76,7 +78,7 @@ def dtype_code(t):
 def conv_igemm(inp, w, out=None, out2=None, *, N, IH, IW, IC, OH, OW, OC, KH, KW, stride=1, dil=1, pad=0,
                mode=0, epi=0, r_pre=None, r_post=None, mask=None, scale=None, shift=None, drop=None,
                ld_in=None, ld_out=None, ld_out2=None, ld_rpre=None, ld_rpost=None, ld_mask=None, relu_out2=1,
-               relu_lt=0, bm_hint=0):
+               relu_lt=0, bm_hint=0, seg2=None):
     d = ConvDesc()
     d.inp, d.w, d.out, d.out2 = _ptr(inp), _ptr(w), _ptr(out), _ptr(out2)
     d.r_pre, d.r_post, d.mask = _ptr(r_pre), _ptr(r_post), _ptr(mask)
@@ -86,6 +88,8 @@ def conv_igemm(inp, w, out=None, out2=None, *, N, IH, IW, IC, OH, OW, OC, KH, KW
     d.ld_rpre, d.ld_rpost, d.ld_mask = ld_rpre or OC, ld_rpost or OC, ld_mask or OC
     d.KH, d.KW, d.stride, d.dil, d.pad = KH, KW, stride, dil, pad
     d.mode, d.epi, d.dtype, d.relu_out2, d.relu_lt, d.bm_hint = mode, epi, dtype_code(inp), relu_out2, relu_lt, bm_hint
+    if seg2 is not None:                         # (IH2, IW2, OH2, OW2): second row segment, same N
+        d.IH2, d.IW2, d.OH2, d.OW2 = seg2
     if PROFILE is not None:                      # bench.py: HIP events on the launch stream around this launch
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
@@ -93,12 +97,14 @@ def conv_igemm(inp, w, out=None, out2=None, *, N, IH, IW, IC, OH, OW, OC, KH, KW
     if PROFILE is not None:
         ev1.record()
         pix = N * (OH * OW if mode == 0 else IH * IW)        # algorithmic: the conv's output pixels
+        if seg2 is not None:
+            pix += N * (seg2[2] * seg2[3] if mode == 0 else seg2[0] * seg2[1])
         PROFILE.append((ev0, ev1, 2.0 * pix * IC * OC * KH * KW,
                         f"{'fwd' if mode == 0 else 'dgrad'} {IC}->{OC} k{KH} s{stride} d{dil} {OH}x{OW}"))
 
 
 def conv_wgrad(x, dy, dw, *, N, IH, IW, IC, OH, OW, OC, KH, KW, stride=1, dil=1, pad=0,
-               ld_x=None, ld_dy=None, split_k=0, IC_dw=None, OC_dw=None, tile_hint=0):
+               ld_x=None, ld_dy=None, split_k=0, IC_dw=None, OC_dw=None, tile_hint=0, seg2=None):
     d = WgradDesc()
     d.x, d.dy, d.dw = _ptr(x), _ptr(dy), _ptr(dw)
     d.N, d.IH, d.IW, d.IC, d.ld_x = N, IH, IW, IC, ld_x or IC
@@ -106,6 +112,8 @@ def conv_wgrad(x, dy, dw, *, N, IH, IW, IC, OH, OW, OC, KH, KW, stride=1, dil=1,
     d.KH, d.KW, d.stride, d.dil, d.pad = KH, KW, stride, dil, pad
     d.dtype, d.split_k = dtype_code(x), split_k
     d.IC_dw, d.OC_dw, d.tile_hint = IC_dw or IC, OC_dw or OC, tile_hint
+    if seg2 is not None:
+        d.IH2, d.IW2, d.OH2, d.OW2 = seg2
     assert dw.dtype == torch.float32
     if PROFILE_WGRAD is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -113,7 +121,8 @@ def conv_wgrad(x, dy, dw, *, N, IH, IW, IC, OH, OW, OC, KH, KW, stride=1, dil=1,
     check(lib.wseg_conv_wgrad(C.byref(d), C.c_void_p(stream_ptr())), "wseg_conv_wgrad")
     if PROFILE_WGRAD is not None:
         ev1.record()
-        PROFILE_WGRAD.append((ev0, ev1, 2.0 * N * OH * OW * IC * OC * KH * KW, f"wgrad {IC}->{OC} k{KH} s{stride} d{dil} {OH}x{OW}"))
+        pix = N * OH * OW + (N * seg2[2] * seg2[3] if seg2 is not None else 0)
+        PROFILE_WGRAD.append((ev0, ev1, 2.0 * pix * IC * OC * KH * KW, f"wgrad {IC}->{OC} k{KH} s{stride} d{dil} {OH}x{OW}"))
 
 
 def pack_weights(master, fwd, tr, OC, T, IC, OCp, ICp, dtype):

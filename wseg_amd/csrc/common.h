@@ -81,6 +81,29 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return start + k;
 }
 
+// Row (pixel) index of a one- or two-segment activation matrix -> image row base, output coordinates and the
+// input geometry of its segment.  Segment 2 (OH2 > 0) follows segment 1's N*OH*OW output rows / N*IH*IW input rows.
+struct wseg_rowgeo { long in_base; int n_glob, oy, ox, IH, IW; };
+template <typename D>
+__device__ __forceinline__ wseg_rowgeo wseg_decode_row(const D& d, int m) {
+  wseg_rowgeo g;
+  const int M1 = d.N * d.OH * d.OW;
+  if (d.OH2 == 0 || m < M1) {
+    const int hw = d.OH * d.OW;
+    const int n = m / hw, rem = m - n * hw;
+    g.oy = rem / d.OW; g.ox = rem - g.oy * d.OW;
+    g.IH = d.IH; g.IW = d.IW; g.n_glob = n;
+    g.in_base = (long)n * d.IH * d.IW;
+  } else {
+    const int mm = m - M1, hw = d.OH2 * d.OW2;
+    const int n = mm / hw, rem = mm - n * hw;
+    g.oy = rem / d.OW2; g.ox = rem - g.oy * d.OW2;
+    g.IH = d.IH2; g.IW = d.IW2; g.n_glob = d.N + n;
+    g.in_base = (long)d.N * d.IH * d.IW + (long)n * d.IH2 * d.IW2;
+  }
+  return g;
+}
+
 void wseg_set_error(const char* fmt, ...);
 #define WSEG_CHECK(cond, ...)           \
   do {                                  \

@@ -53,8 +53,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const Args a) {
   // ---- staging assignment: thread -> 4 A rows + 4 B rows, one 16-B chunk each per K-step
   const int srow = lane >> 3;                      // row within an 8-row DMA piece
   const int pch = lane & 7;                        // physical 16-B chunk in the 128-B row
-  int a_iy0[AI], a_ix0[AI];
-  long a_img[AI];                                  // n*IH*IW, or -1 when the row is beyond M
+  int a_iy0[AI], a_ix0[AI], a_H[AI], a_W[AI];
+  long a_img[AI];                                  // first input row of the image, or -1 when the row is beyond M
   const char* bptr[4];
   int b_inc[4];
   int lch[4];                                      // logical chunk this lane fetches for B piece i
@@ -65,14 +65,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const Args a) {
     lcha[i] = pch ^ ((r >> 1) & 7);
     const int m = m0 + r;
     if (m < a.M) {
-      const int hw = d.OH * d.OW;
-      const int n = m / hw, rem = m - n * hw;
-      const int oy = rem / d.OW, ox = rem - oy * d.OW;
-      a_img[i] = (long)n * d.IH * d.IW;
+      const wseg_rowgeo rg = wseg_decode_row(d, m);
+      const int oy = rg.oy, ox = rg.ox;
+      a_img[i] = rg.in_base; a_H[i] = rg.IH; a_W[i] = rg.IW;
       if (d.mode == 0) { a_iy0[i] = oy * d.stride - d.pad; a_ix0[i] = ox * d.stride - d.pad; }
       else             { a_iy0[i] = oy + d.pad;            a_ix0[i] = ox + d.pad; }
     } else {
-      a_img[i] = -1; a_iy0[i] = 0; a_ix0[i] = 0;
+      a_img[i] = -1; a_iy0[i] = 0; a_ix0[i] = 0; a_H[i] = 1; a_W[i] = 1;
     }
   }
 #pragma unroll
@@ -102,9 +101,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const Args a) {
         if (d.stride == 1) { iy = ty; ix = tx; }
         else { iy = ty / d.stride; ix = tx / d.stride; ok = ok && (iy * d.stride == ty) && (ix * d.stride == tx); }
       }
-      ok = ok && iy >= 0 && iy < d.IH && ix >= 0 && ix < d.IW && d.bm_hint != -1;   // (-1: timing diagnostic, A from the zero page)
+      ok = ok && iy >= 0 && iy < a_H[i] && ix >= 0 && ix < a_W[i] && d.bm_hint != -1;   // (-1: timing diagnostic, A from the zero page)
       if (ok) {
-        aptr[i] = IN + ((size_t)(a_img[i] + (long)iy * d.IW + ix) * d.ld_in + (size_t)lcha[i] * CH) * ES;
+        aptr[i] = IN + ((size_t)(a_img[i] + (long)iy * a_W[i] + ix) * d.ld_in + (size_t)lcha[i] * CH) * ES;
         a_inc[i] = ROWB;
       } else {
         aptr[i] = zero + pch * 16; a_inc[i] = 0;
@@ -202,7 +201,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const Args a) {
   // are loaded before any of them is consumed: one memory round trip per chunk instead of one per row
   // (the dependent-load chain was the whole cost of short-K layers).  Rows beyond M are clamped to
   // row 0 for the loads and predicated off at the stores (no divergent control flow).
-  const int hw = d.OH * d.OW;
   const int cv = (tid & 15) * 8;
   const int oc_raw = n0 + cv;
   const bool col_ok = oc_raw < d.OC;                        // OC is a multiple of 8 (host-checked)
@@ -240,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const Args a) {
     }
     if (EPI != 2 && has_drop) {
 #pragma unroll
-      for (int j = 0; j < CHK; ++j) load8<WSEG_F32>(d.drop, (mrow[j] / hw) * d.OC + oc, dr[j]);
+      for (int j = 0; j < CHK; ++j) load8<WSEG_F32>(d.drop, (size_t)wseg_decode_row(d, (int)mrow[j]).n_glob * d.OC + oc, dr[j]);
     }
 #pragma unroll
     for (int j = 0; j < CHK; ++j) {
@@ -316,7 +314,8 @@ extern "C" int wseg_conv_igemm(const wseg_conv_desc* d, void* stream) {
   if (d->r_pre) WSEG_CHECK(d->ld_rpre % 8 == 0, "conv_igemm: bad ld_rpre");
   if (d->r_post) WSEG_CHECK(d->ld_rpost % 8 == 0, "conv_igemm: bad ld_rpost");
   if (d->mask) WSEG_CHECK(d->ld_mask % 8 == 0, "conv_igemm: bad ld_mask");
-  const long M = (long)d->N * d->OH * d->OW;
+  const long M = (long)d->N * d->OH * d->OW + (long)d->N * d->OH2 * d->OW2;
+  WSEG_CHECK(d->OH2 >= 0 && (d->OH2 == 0 || (d->OW2 > 0 && d->IH2 > 0 && d->IW2 > 0)), "conv_igemm: bad second segment");
   WSEG_CHECK(M < (1L << 31) && (long)d->N * d->IH * d->IW * d->ld_in < (1L << 40), "conv_igemm: tensor too large");
   Args a;
   a.d = *d;

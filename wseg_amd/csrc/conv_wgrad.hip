@@ -90,7 +90,7 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void conv_wgrad_kernel(const Args 
 
   // pixel coordinates of the rows this thread stages for X (advanced by PK per step)
   constexpr int CPR_I = ROWB_I / 16, CPR_O = ROWB_O / 16;          // chunks per row
-  int xr[PI], xlc[PI], cn[PI], cy[PI], cx[PI];
+  int xr[PI], xlc[PI];
   bool xok[PI];
 #pragma unroll
   for (int i = 0; i < PI; ++i) {
@@ -98,10 +98,6 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void conv_wgrad_kernel(const Args 
     xr[i] = ci / CPR_I;
     xlc[i] = logical_chunk(xr[i], ci % CPR_I);
     xok[i] = (ic0 + xlc[i] * CH) < d.IC;
-    const int m = m_begin + xr[i];
-    const int hw = d.OH * d.OW;
-    const int n = m / hw, rem = m - n * hw;
-    cn[i] = n; cy[i] = rem / d.OW; cx[i] = rem - cy[i] * d.OW;
   }
   int yr[PO], ylc[PO];
   bool yok[PO];
@@ -128,14 +124,13 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void conv_wgrad_kernel(const Args 
       const int m = mstep + xr[i];
       const char* pi = zero + (lane & 15) * 16;
       if (m < m_end && xok[i]) {
-        const int iy = cy[i] * d.stride + ky * d.dil - d.pad;
-        const int ix = cx[i] * d.stride + kx * d.dil - d.pad;
-        if (iy >= 0 && iy < d.IH && ix >= 0 && ix < d.IW)
-          pi = X + (((size_t)cn[i] * d.IH + iy) * d.IW + ix) * (size_t)d.ld_x * ES + (size_t)(ic0 + xlc[i] * CH) * ES;
+        const wseg_rowgeo rg = wseg_decode_row(d, m);
+        const int iy = rg.oy * d.stride + ky * d.dil - d.pad;
+        const int ix = rg.ox * d.stride + kx * d.dil - d.pad;
+        if (iy >= 0 && iy < rg.IH && ix >= 0 && ix < rg.IW)
+          pi = X + ((size_t)(rg.in_base + (long)iy * rg.IW + ix) * d.ld_x + (size_t)(ic0 + xlc[i] * CH)) * ES;
       }
       glds16(pi, li + (wid * PI + i) * 1024);
-      cx[i] += PK;
-      while (cx[i] >= d.OW) { cx[i] -= d.OW; if (++cy[i] == d.OH) { cy[i] = 0; ++cn[i]; } }
     }
   };
 
@@ -288,16 +283,11 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pipe_kernel(const Args a) {
   // staging: thread -> rows r0 = tid>>4 and r0+32 of every half-tile, physical 16-B chunk tid&15
   const int pch = tid & 15;
   int rr[2], lc[2];
-  int cn[2], cy[2], cx[2];                          // pixel coordinates of the NEXT X tile to issue
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     rr[k] = (tid >> 4) + 32 * k;
     const int sw = (rr[k] & 3) | (((rr[k] >> 3) & 1) << 2);
     lc[k] = (((pch >> 1) ^ sw) << 1) | (pch & 1);
-    const int m = m_begin + rr[k];
-    const int hw = d.OH * d.OW;
-    const int n = m / hw, rem = m - n * hw;
-    cn[k] = n; cy[k] = rem / d.OW; cx[k] = rem - cy[k] * d.OW;
   }
   const char* xrow[2];                               // source pixel row of the X tile being issued (or nullptr)
   auto x_prepare = [&](int kt) {                     // call once per X tile, before its two half issues
@@ -306,13 +296,12 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pipe_kernel(const Args a) {
       const int m = m_begin + kt * PK + rr[k];
       xrow[k] = nullptr;
       if (m < m_end) {
-        const int iy = cy[k] * d.stride + ky * d.dil - d.pad;
-        const int ix = cx[k] * d.stride + kx * d.dil - d.pad;
-        if (iy >= 0 && iy < d.IH && ix >= 0 && ix < d.IW)
-          xrow[k] = X + (size_t)((cn[k] * d.IH + iy) * d.IW + ix) * d.ld_x * 2;
+        const wseg_rowgeo rg = wseg_decode_row(d, m);
+        const int iy = rg.oy * d.stride + ky * d.dil - d.pad;
+        const int ix = rg.ox * d.stride + kx * d.dil - d.pad;
+        if (iy >= 0 && iy < rg.IH && ix >= 0 && ix < rg.IW)
+          xrow[k] = X + (size_t)(rg.in_base + (long)iy * rg.IW + ix) * d.ld_x * 2;
       }
-      cx[k] += PK;
-      while (cx[k] >= d.OW) { cx[k] -= d.OW; if (++cy[k] == d.OH) { cy[k] = 0; ++cn[k]; } }
     }
   };
   auto issue_x = [&](int h, int buf) {
@@ -471,7 +460,8 @@ extern "C" int wseg_conv_wgrad(const wseg_wgrad_desc* d, void* stream) {
   WSEG_CHECK(d->ld_x >= d->IC && d->ld_dy >= d->OC, "conv_wgrad: leading dims too small");
   WSEG_CHECK(d->IC_dw > 0 && d->IC_dw <= d->IC && d->OC_dw > 0 && d->OC_dw <= d->OC, "conv_wgrad: bad dw extents");
   WSEG_CHECK(d->N > 0 && d->OH > 0 && d->OW > 0 && d->IH > 0 && d->IW > 0 && d->stride >= 1 && d->dil >= 1, "conv_wgrad: bad shape");
-  const long M = (long)d->N * d->OH * d->OW;
+  const long M = (long)d->N * d->OH * d->OW + (long)d->N * d->OH2 * d->OW2;
+  WSEG_CHECK(d->OH2 >= 0 && (d->OH2 == 0 || (d->OW2 > 0 && d->IH2 > 0 && d->IW2 > 0)), "conv_wgrad: bad second segment");
   WSEG_CHECK(M < (1L << 31), "conv_wgrad: too many pixels");
   const bool big = d->dtype == WSEG_BF16 && d->OC >= 256 && d->IC >= 256 && d->tile_hint != 128 &&
                    (M >= 16384 || d->tile_hint == 256);   // few pixels: the 128^2 geometry fills the chip better

@@ -198,54 +198,77 @@ class Engine:
         if need_grad:
             anchor = self.flat_w.new_zeros((), requires_grad=True)
             return _NetFunction.apply(x, anchor, self, lowres)
-        outs, _ = self.run_forward(x, save=False, lowres=lowres)
-        return outs
+        outs, _ = self.run_forward([x], save=False, lowres=lowres)
+        return outs[0]
 
-    def run_forward(self, x, save, lowres=False):
+    def run_forward(self, xs, save, lowres=False):
+        """xs: list of one or two image batches (same N).  Two views are BATCHED: every activation is one row
+        matrix [rows(view 1) ++ rows(view 2)][C] and every conv / wgrad is ONE launch over both row segments
+        (the 128x128 view alone cannot fill the chip).  Returns ([per-view output tuple], saved context)."""
         net = self.net
-        dev = x.device
+        V = len(xs)
+        assert V in (1, 2)
+        dev = xs[0].device
         dt = L.BF16 if net.precision == "bf16" else L.F32
         tdt = L.TORCH_DTYPE[dt]
         P = self.ensure_packs(dev, dt)
-        N, _, H, W = x.shape
-        masks = self._masks(N, dev)
-        S = {"masks": masks, "dims": {}, "N": N, "H": H, "W": W, "dt": dt, "x": x}
+        N = xs[0].shape[0]
+        assert all(x.shape[0] == N for x in xs)
+        per_view_masks = [self._masks(N, dev) for _ in range(V)]
+        masks = None
+        if per_view_masks[0] is not None:
+            masks = {k: torch.cat([m[k] for m in per_view_masks], dim=0).contiguous() for k in per_view_masks[0]}
+        S = {"masks": masks, "dims": {}, "N": N, "V": V, "dt": dt, "xs": xs, "lowres": lowres}
 
-        def E(*shape):
-            return torch.empty(shape, device=dev, dtype=tdt)
+        def rows_of(dims):
+            return sum(N * h * w for (h, w) in dims)
+
+        def offs_of(dims):
+            o, out = 0, []
+            for (h, w) in dims:
+                out.append(o)
+                o += N * h * w
+            return out
+
+        def E(m, c):
+            return torch.empty((m, c), device=dev, dtype=tdt)
+
+        def conv(inp, wname, out, out2, cin, cout, k, stride, dil, din, dout, **kw):
+            seg2 = (din[1][0], din[1][1], dout[1][0], dout[1][1]) if V == 2 else None
+            L.conv_igemm(inp, P["w"][wname], out, out2, N=N, IH=din[0][0], IW=din[0][1], IC=cin, OH=dout[0][0], OW=dout[0][1],
+                         OC=cout, KH=k, KW=k, stride=stride, dil=dil, pad=dil * (k // 2), seg2=seg2, **kw)
 
         def next_bn(i):
             if i + 1 < len(arch.BLOCKS):
                 return P["bn"][arch.BLOCKS[i + 1][0] + ".bn_branch2a"], None
             return P["bn"]["bn7"], (masks["dropout7"] if masks else None)
 
+        dims = [(x.shape[2], x.shape[3]) for x in xs]
         sc, sh = P["bn"]["b2.bn_branch2a"]
-        t = E(N, H, W, 64)
-        L.stem_conv(x, net.conv1a.weight.detach(), sc, sh, None, t, N, H, W, dt)
-        xraw, h, w = None, H, W
+        t = E(rows_of(dims), 64)
+        for x, off, (H, W) in zip(xs, offs_of(dims), dims):
+            L.stem_conv(x, net.conv1a.weight.detach(), sc, sh, None, t[off:], N, H, W, dt)
+        xraw = None
         for i, b in enumerate(arch.BLOCKS):
             name, kind, cin, mid, cout, stride, fd, d, p = b
             same = arch.block_same_shape(b)
             (nsc, nsh), ndrop = next_bn(i)
             nxt_same = i + 1 < len(arch.BLOCKS) and arch.block_same_shape(arch.BLOCKS[i + 1])
-            oh, ow = _out_size(h, 3 if kind == "res" else 1, stride, fd if kind == "res" else 1), \
-                _out_size(w, 3 if kind == "res" else 1, stride, fd if kind == "res" else 1)
-            geo = dict(N=N)
+            k0 = 3 if kind == "res" else 1
+            odims = [(_out_size(h, k0, stride, fd if kind == "res" else 1), _out_size(w, k0, stride, fd if kind == "res" else 1)) for (h, w) in dims]
+            Mo = rows_of(odims)
             if kind == "res":
                 s1, sh1 = P["bn"][name + ".bn_branch2b1"]
-                v = E(N, oh, ow, mid)
-                L.conv_igemm(t, P["w"][name + ".conv_branch2a"], None, v, IH=h, IW=w, IC=cin, OH=oh, OW=ow, OC=mid,
-                             KH=3, KW=3, stride=stride, dil=fd, pad=fd, scale=s1, shift=sh1, **geo)
+                v = E(Mo, mid)
+                conv(t, name + ".conv_branch2a", None, v, cin, mid, 3, stride, fd, dims, odims, scale=s1, shift=sh1)
                 if same:
                     rpost = xraw
                 else:
-                    rpost = E(N, oh, ow, cout)
-                    L.conv_igemm(t, P["w"][name + ".conv_branch1"], rpost, IH=h, IW=w, IC=cin, OH=oh, OW=ow, OC=cout,
-                                 KH=1, KW=1, stride=stride, **geo)
-                xn = E(N, oh, ow, cout) if nxt_same else None
-                tn = E(N, oh, ow, cout)
-                L.conv_igemm(v, P["w"][name + ".conv_branch2b1"], xn, tn, IH=oh, IW=ow, IC=mid, OH=oh, OW=ow, OC=cout,
-                             KH=3, KW=3, dil=d, pad=d, r_post=rpost, scale=nsc, shift=nsh, drop=ndrop, **geo)
+                    rpost = E(Mo, cout)
+                    conv(t, name + ".conv_branch1", rpost, None, cin, cout, 1, stride, 1, dims, odims)
+                xn = E(Mo, cout) if nxt_same else None
+                tn = E(Mo, cout)
+                conv(v, name + ".conv_branch2b1", xn, tn, mid, cout, 3, 1, d, odims, odims, r_post=rpost, scale=nsc, shift=nsh, drop=ndrop)
                 if save:
                     S[name] = dict(t=t, v=v)
             else:
@@ -254,151 +277,182 @@ class Engine:
                 s2, sh2 = P["bn"][name + ".bn_branch2b2"]
                 d1 = masks[name + ".dropout_2b1"] if masks else None
                 d2 = masks[name + ".dropout_2b2"] if masks else None
-                v1 = E(N, oh, ow, c4)
-                L.conv_igemm(t, P["w"][name + ".conv_branch2a"], None, v1, IH=h, IW=w, IC=cin, OH=oh, OW=ow, OC=c4,
-                             KH=1, KW=1, stride=stride, scale=s1, shift=sh1, drop=d1, **geo)
-                v2 = E(N, oh, ow, c2)
-                L.conv_igemm(v1, P["w"][name + ".conv_branch2b1"], None, v2, IH=oh, IW=ow, IC=c4, OH=oh, OW=ow, OC=c2,
-                             KH=3, KW=3, dil=d, pad=d, scale=s2, shift=sh2, drop=d2, **geo)
-                b1 = E(N, oh, ow, cout)
-                L.conv_igemm(t, P["w"][name + ".conv_branch1"], b1, IH=h, IW=w, IC=cin, OH=oh, OW=ow, OC=cout,
-                             KH=1, KW=1, stride=stride, **geo)
+                v1 = E(Mo, c4)
+                conv(t, name + ".conv_branch2a", None, v1, cin, c4, 1, stride, 1, dims, odims, scale=s1, shift=sh1, drop=d1)
+                v2 = E(Mo, c2)
+                conv(v1, name + ".conv_branch2b1", None, v2, c4, c2, 3, 1, d, odims, odims, scale=s2, shift=sh2, drop=d2)
+                b1 = E(Mo, cout)
+                conv(t, name + ".conv_branch1", b1, None, cin, cout, 1, stride, 1, dims, odims)
                 xn = None
-                tn = E(N, oh, ow, cout)
-                L.conv_igemm(v2, P["w"][name + ".conv_branch2b2"], xn, tn, IH=oh, IW=ow, IC=c2, OH=oh, OW=ow, OC=cout,
-                             KH=1, KW=1, r_post=b1, scale=nsc, shift=nsh, drop=ndrop, **geo)
+                tn = E(Mo, cout)
+                conv(v2, name + ".conv_branch2b2", xn, tn, c2, cout, 1, 1, 1, odims, odims, r_post=b1, scale=nsc, shift=nsh, drop=ndrop)
                 if save:
                     S[name] = dict(t=t, v1=v1, v2=v2)
-            S["dims"][name] = (h, w, oh, ow)
+            S["dims"][name] = (dims, odims)
             if name == "b5":
                 conv4 = t
             if name == "b6":
                 conv5 = t
-            t, xraw, h, w = tn, xn, oh, ow
+            t, xraw, dims = tn, xn, odims
 
-        fea = t                                               # relu(bn7(x)) * dropout7   [N,h,w,4096]
-        hw = h * w
-        head = E(N, h, w, HEAD_LD)
-        L.conv_igemm(fea, P["w"]["head"], head, N=N, IH=h, IW=w, IC=4096, OH=h, OW=w, OC=HEAD_LD, KH=1, KW=1, relu_lt=128)
-        cam_low = torch.empty(N, 21, h, w, device=dev, dtype=torch.float32)
-        cmax = torch.empty(N, 21, device=dev, dtype=torch.float32)
-        L.head_split(head, HEAD_LD, 128, cam_low, cmax, N, hw)
-        G = torch.empty(N * hw, 32, device=dev, dtype=torch.float32)
-        L.cam_gate(cam_low, cmax, G, N, hw)
-        feat = E(N, h, w, FEAT_LD)
-        L.conv_igemm(conv4, P["w"]["f8_3"], feat, N=N, IH=h, IW=w, IC=512, OH=h, OW=w, OC=64, KH=1, KW=1, epi=2, ld_out=FEAT_LD)
-        L.conv_igemm(conv5, P["w"]["f8_4"], feat.view(-1)[64:], N=N, IH=h, IW=w, IC=1024, OH=h, OW=w, OC=128, KH=1, KW=1,
-                     epi=2, ld_out=FEAT_LD)
-        L.pcm_xs(x, feat, FEAT_LD, 192, FEAT_LD, N, H, W, h, w)
-        Fm = E(N, h, w, 192)
-        L.conv_igemm(feat, P["w"]["f9"], Fm, N=N, IH=h, IW=w, IC=FEAT_LD, OH=h, OW=w, OC=192, KH=1, KW=1)
-        Fh = torch.empty(N * hw, 192, device=dev, dtype=torch.float32)
-        nrm = torch.empty(N * hw, device=dev, dtype=torch.float32)
-        L.l2norm_forward(Fm, 192, Fh, nrm, N * hw)
-        rvd = torch.empty(N, 21, h, w, device=dev, dtype=torch.float32)
-        den = torch.empty(N, hw, device=dev, dtype=torch.float32)
+        fea = t                                               # relu(bn7(x)) * dropout7   [M,4096]
+        M = rows_of(dims)
+        offs = offs_of(dims)
+        head = E(M, HEAD_LD)
+        conv(fea, "head", head, None, 4096, HEAD_LD, 1, 1, 1, dims, dims, relu_lt=128)
+        feat = E(M, FEAT_LD)
+        conv(conv4, "f8_3", feat, None, 512, 64, 1, 1, 1, dims, dims, epi=2, ld_out=FEAT_LD)
+        conv(conv5, "f8_4", feat.view(-1)[64:], None, 1024, 128, 1, 1, 1, dims, dims, epi=2, ld_out=FEAT_LD)
+        G = torch.empty(M, 32, device=dev, dtype=torch.float32)
+        views = []
+        for x, off, (h, w) in zip(xs, offs, dims):
+            hw = h * w
+            cam_low = torch.empty(N, 21, h, w, device=dev, dtype=torch.float32)
+            cmax = torch.empty(N, 21, device=dev, dtype=torch.float32)
+            L.head_split(head[off:], HEAD_LD, 128, cam_low, cmax, N, hw)
+            L.cam_gate(cam_low, cmax, G[off:], N, hw)
+            L.pcm_xs(x, feat[off:], FEAT_LD, 192, FEAT_LD, N, x.shape[2], x.shape[3], h, w)
+            views.append(dict(h=h, w=w, H=x.shape[2], W=x.shape[3], off=off, rows=N * hw, cam_low=cam_low))
+        Fm = E(M, 192)
+        conv(feat, "f9", Fm, None, FEAT_LD, 192, 1, 1, 1, dims, dims)
+        Fh = torch.empty(M, 192, device=dev, dtype=torch.float32)
+        nrm = torch.empty(M, device=dev, dtype=torch.float32)
+        L.l2norm_forward(Fm, 192, Fh, nrm, M)
         Fb = Gb = None
         if dt == L.BF16:                                      # bf16-MFMA PCM (throughput mode); fp32 mode keeps the exact-f32 kernel
-            Fb = torch.empty(N * hw, 192, device=dev, dtype=torch.bfloat16)
-            Gb = torch.empty(N * hw, 32, device=dev, dtype=torch.bfloat16)
+            Fb = torch.empty(M, 192, device=dev, dtype=torch.bfloat16)
+            Gb = torch.empty(M, 32, device=dev, dtype=torch.bfloat16)
             L.to_bf16(Fh, Fb)
             L.to_bf16(G, Gb)
-            L.pcm_forward_bf16(Fb, Gb, rvd, den, N, hw)
-        else:
-            L.pcm_forward(Fh, G, rvd, den, N, hw)
-        f_proj = head[..., :128].permute(0, 3, 1, 2)
-        if lowres:
-            outs = (cam_low, rvd, f_proj, head)
-        else:
-            cam = torch.empty(N, 21, H, W, device=dev, dtype=torch.float32)
-            cam_rv = torch.empty(N, 21, H, W, device=dev, dtype=torch.float32)
-            L.resize_planar_fwd(cam_low, cam, N * 21, h, w, H, W, True)
-            L.resize_planar_fwd(rvd, cam_rv, N * 21, h, w, H, W, True)
-            outs = (cam, cam_rv, f_proj.float() if dt == L.BF16 else f_proj, rvd)
+        outs = []
+        for vw, x in zip(views, xs):
+            h, w, off, hw = vw["h"], vw["w"], vw["off"], vw["h"] * vw["w"]
+            rvd = torch.empty(N, 21, h, w, device=dev, dtype=torch.float32)
+            den = torch.empty(N, hw, device=dev, dtype=torch.float32)
+            if dt == L.BF16:
+                L.pcm_forward_bf16(Fb[off:], Gb[off:], rvd, den, N, hw)
+            else:
+                L.pcm_forward(Fh[off:], G[off:], rvd, den, N, hw)
+            head_v = head[off:off + N * hw].view(N, h, w, HEAD_LD)
+            f_proj = head_v[..., :128].permute(0, 3, 1, 2)
+            if lowres:
+                outs.append((vw["cam_low"], rvd, f_proj, head_v))
+            else:
+                H, W = vw["H"], vw["W"]
+                cam = torch.empty(N, 21, H, W, device=dev, dtype=torch.float32)
+                cam_rv = torch.empty(N, 21, H, W, device=dev, dtype=torch.float32)
+                L.resize_planar_fwd(vw["cam_low"], cam, N * 21, h, w, H, W, True)
+                L.resize_planar_fwd(rvd, cam_rv, N * 21, h, w, H, W, True)
+                outs.append((cam, cam_rv, f_proj.float() if dt == L.BF16 else f_proj, rvd))
+            vw.update(rvd=rvd.clone() if save else None, den=den)
         if save:
-            S.update(fea=fea, head=head, G=G, feat=feat, Fm=Fm, Fh=Fh, Fb=Fb, Gb=Gb, nrm=nrm, rvd=rvd.clone(), den=den,
-                     conv4=conv4, conv5=conv5, h=h, w=w, lowres=lowres)
+            S.update(fea=fea, head=head, G=G, feat=feat, Fm=Fm, Fh=Fh, Fb=Fb, Gb=Gb, nrm=nrm, conv4=conv4, conv5=conv5,
+                     views=views, hdims=dims, M=M)
         return outs, S
 
     # ------------------------------------------------------------------ backward
-    def run_backward(self, S, g_cam, g_cam_rv, g_fproj, g_rvd, d_head_rows=None):
-        """Gradients of the 4 outputs -> accumulates into flat_g.  In the fused (lowres) path
-        g_cam / g_cam_rv are already gradients of the stride-8 maps and d_head_rows may be supplied
-        directly (rows [f_proj | cam | pad])."""
-        net = self.net
+    def run_backward(self, S, grads, d_head_rows=None):
+        """grads: per view (g_cam, g_cam_rv, g_fproj, g_rvd) — gradients of the view's four outputs (any may be
+        None); in the fused (lowres) path g_cam / g_cam_rv are gradients of the stride-8 maps and `d_head_rows`
+        (joint rows [f_proj | cam | pad]) may be supplied directly.  Accumulates into flat_g."""
         P = self.packs
         dt = S["dt"]
         tdt = L.TORCH_DTYPE[dt]
-        N, H, W, h, w = S["N"], S["H"], S["W"], S["h"], S["w"]
-        hw = h * w
+        N, V, M = S["N"], S["V"], S["M"]
+        hdims = S["hdims"]
         dev = S["fea"].device
         masks = S["masks"]
         self.attach_grads()
 
-        def E(*shape):
-            return torch.empty(shape, device=dev, dtype=tdt)
+        def E(m, c):
+            return torch.empty((m, c), device=dev, dtype=tdt)
+
+        def rows_of(dims):
+            return sum(N * h * w for (h, w) in dims)
 
         def trainable(nm):
             return self.conv_param(nm).requires_grad
 
-        def wgrad(nm, x, dy, **kw):
+        def seg(din, dout):
+            return (din[1][0], din[1][1], dout[1][0], dout[1][1]) if V == 2 else None
+
+        def wgrad(nm, x, dy, cin, cout, k, stride, dil, din, dout, **kw):
             if trainable(nm):
                 off, n = self.offsets[nm]
-                L.conv_wgrad(x, dy, self.flat_g[off:off + n], **kw)
+                L.conv_wgrad(x, dy, self.flat_g[off:off + n], N=N, IH=din[0][0], IW=din[0][1], IC=cin, OH=dout[0][0], OW=dout[0][1],
+                             OC=cout, KH=k, KW=k, stride=stride, dil=dil, pad=dil * (k // 2), seg2=seg(din, dout), **kw)
 
-        # ---- upsample adjoints
-        if S["lowres"]:
-            d_cam_low, d_rvd = g_cam, g_cam_rv
-        else:
-            d_cam_low = None
+        def dgrad(dy, wname, out, conv_cin, conv_cout, k, stride, dil, din, dout, **kw):
+            # in = dY over the conv's OUTPUT dims (dout), out = dX over its INPUT dims (din)
+            seg2 = (dout[1][0], dout[1][1], din[1][0], din[1][1]) if V == 2 else None
+            L.conv_igemm(dy, P["wt"][wname], out, None, N=N, IH=dout[0][0], IW=dout[0][1], IC=conv_cout, OH=din[0][0], OW=din[0][1],
+                         OC=conv_cin, KH=k, KW=k, stride=stride, dil=dil, pad=dil * (k // 2), mode=1, seg2=seg2, **kw)
+
+        # ---- per-view adjoints of the x8 upsamples / gather of the stride-8 gradients
+        d_cam_low, d_rvd = [], []
+        for vw, (g_cam, g_cam_rv, g_fproj, g_rvd) in zip(S["views"], grads):
+            h, w, H, W = vw["h"], vw["w"], vw["H"], vw["W"]
+            if S["lowres"]:
+                d_cam_low.append(g_cam)
+                d_rvd.append(g_cam_rv)
+                continue
+            dc = None
             if g_cam is not None:
-                d_cam_low = torch.empty(N, 21, h, w, device=dev, dtype=torch.float32)
-                L.resize_planar_bwd(g_cam.contiguous().float(), d_cam_low, N * 21, h, w, H, W, True)
-            d_rvd = None
+                dc = torch.empty(N, 21, h, w, device=dev, dtype=torch.float32)
+                L.resize_planar_bwd(g_cam.contiguous().float(), dc, N * 21, h, w, H, W, True)
+            dr = None
             if g_cam_rv is not None:
-                d_rvd = torch.empty(N, 21, h, w, device=dev, dtype=torch.float32)
-                L.resize_planar_bwd(g_cam_rv.contiguous().float(), d_rvd, N * 21, h, w, H, W, True)
+                dr = torch.empty(N, 21, h, w, device=dev, dtype=torch.float32)
+                L.resize_planar_bwd(g_cam_rv.contiguous().float(), dr, N * 21, h, w, H, W, True)
             if g_rvd is not None:
-                d_rvd = g_rvd.contiguous().float() if d_rvd is None else d_rvd + g_rvd
+                dr = g_rvd.contiguous().float() if dr is None else dr + g_rvd
+            d_cam_low.append(dc)
+            d_rvd.append(dr)
         # ---- PCM branch -> f9, f8_3, f8_4
-        if d_rvd is not None:
-            DN = torch.empty(N * hw, 32, device=dev, dtype=torch.float32)
-            dFh = torch.zeros(N * hw, 192, device=dev, dtype=torch.float32)
-            if S["Fb"] is not None:
-                DNb = torch.empty(N * hw, 32, device=dev, dtype=torch.bfloat16)
-                L.pcm_backward_bf16(S["Fb"], S["Gb"], d_rvd.contiguous(), S["rvd"], S["den"], DN, DNb, dFh, N, hw)
-            else:
-                L.pcm_backward(S["Fh"], S["G"], d_rvd.contiguous(), S["rvd"], S["den"], DN, dFh, N, hw)
-            dF = E(N, h, w, 192)
-            L.l2norm_backward(S["Fm"], 192, dFh, S["nrm"], dF, 192, N * hw)
+        if any(d is not None for d in d_rvd):
+            DN = torch.empty(M, 32, device=dev, dtype=torch.float32)
+            dFh = torch.zeros(M, 192, device=dev, dtype=torch.float32)
+            DNb = torch.empty(M, 32, device=dev, dtype=torch.bfloat16) if S["Fb"] is not None else None
+            for vw, dr in zip(S["views"], d_rvd):
+                if dr is None:
+                    continue
+                off, hw = vw["off"], vw["h"] * vw["w"]
+                if S["Fb"] is not None:
+                    L.pcm_backward_bf16(S["Fb"][off:], S["Gb"][off:], dr.contiguous(), vw["rvd"], vw["den"], DN[off:], DNb[off:], dFh[off:], N, hw)
+                else:
+                    L.pcm_backward(S["Fh"][off:], S["G"][off:], dr.contiguous(), vw["rvd"], vw["den"], DN[off:], dFh[off:], N, hw)
+            dF = E(M, 192)
+            L.l2norm_backward(S["Fm"], 192, dFh, S["nrm"], dF, 192, M)
             if trainable("f9"):
                 g9 = torch.zeros(192, 195, device=dev, dtype=torch.float32)
-                L.conv_wgrad(S["feat"], dF, g9, N=N, IH=h, IW=w, IC=FEAT_LD, OH=h, OW=w, OC=192, KH=1, KW=1, IC_dw=195)
+                L.conv_wgrad(S["feat"], dF, g9, N=N, IH=hdims[0][0], IW=hdims[0][1], IC=FEAT_LD, OH=hdims[0][0], OW=hdims[0][1], OC=192,
+                             KH=1, KW=1, IC_dw=195, seg2=seg(hdims, hdims))
                 gv = self.grad_view("f9").reshape(192, 195)
                 gv[:, 3:67] += g9[:, 0:64]
                 gv[:, 67:195] += g9[:, 64:192]
                 gv[:, 0:3] += g9[:, 192:195]
             if trainable("f8_3") or trainable("f8_4"):
-                d_feat = E(N, h, w, FEAT_LD)
-                L.conv_igemm(dF, P["wt"]["f9"], d_feat, N=N, IH=h, IW=w, IC=192, OH=h, OW=w, OC=FEAT_LD, KH=1, KW=1,
-                             mode=1, epi=1, mask=S["feat"])
-                wgrad("f8_3", S["conv4"], d_feat, N=N, IH=h, IW=w, IC=512, OH=h, OW=w, OC=64, KH=1, KW=1, ld_dy=FEAT_LD)
-                wgrad("f8_4", S["conv5"], d_feat.view(-1)[64:], N=N, IH=h, IW=w, IC=1024, OH=h, OW=w, OC=128, KH=1, KW=1, ld_dy=FEAT_LD)
+                d_feat = E(M, FEAT_LD)
+                dgrad(dF, "f9", d_feat, FEAT_LD, 192, 1, 1, 1, hdims, hdims, epi=1, mask=S["feat"])
+                wgrad("f8_3", S["conv4"], d_feat, 512, 64, 1, 1, 1, hdims, hdims, ld_dy=FEAT_LD)
+                wgrad("f8_4", S["conv5"], d_feat.view(-1)[64:], 1024, 128, 1, 1, 1, hdims, hdims, ld_dy=FEAT_LD)
         # ---- head
         if d_head_rows is None:
-            if d_cam_low is None and g_fproj is None:
+            if all(dc is None for dc in d_cam_low) and all(g[2] is None for g in grads):
                 return
-            d_head_rows = E(N, h, w, HEAD_LD)
-            gf = g_fproj.contiguous().float() if g_fproj is not None else None
-            L.head_grad_rows(gf, d_cam_low.contiguous() if d_cam_low is not None else None, S["head"], d_head_rows, HEAD_LD, N, hw)
+            d_head_rows = E(M, HEAD_LD)
+            for vw, dc, g in zip(S["views"], d_cam_low, grads):
+                off, hw = vw["off"], vw["h"] * vw["w"]
+                gf = g[2].contiguous().float() if g[2] is not None else None
+                L.head_grad_rows(gf, dc.contiguous() if dc is not None else None, S["head"][off:], d_head_rows[off:], HEAD_LD, N, hw)
         if trainable("fc_proj") or trainable("fc8"):
             off, _ = self.offsets["fc_proj"]
-            L.conv_wgrad(S["fea"], d_head_rows, self.flat_g[off:off + 149 * 4096], N=N, IH=h, IW=w, IC=4096, OH=h, OW=w,
-                         OC=HEAD_LD, KH=1, KW=1, OC_dw=149)
+            L.conv_wgrad(S["fea"], d_head_rows, self.flat_g[off:off + 149 * 4096], N=N, IH=hdims[0][0], IW=hdims[0][1], IC=4096,
+                         OH=hdims[0][0], OW=hdims[0][1], OC=HEAD_LD, KH=1, KW=1, OC_dw=149, seg2=seg(hdims, hdims))
         s7, _ = P["bn"]["bn7"]
-        D = E(N, h, w, 4096)
-        L.conv_igemm(d_head_rows, P["wt"]["head"], D, N=N, IH=h, IW=w, IC=HEAD_LD, OH=h, OW=w, OC=4096, KH=1, KW=1,
-                     mode=1, epi=1, scale=s7, drop=masks["dropout7"] if masks else None, mask=S["fea"])
+        D = E(M, 4096)
+        dgrad(d_head_rows, "head", D, 4096, HEAD_LD, 1, 1, 1, hdims, hdims, epi=1, scale=s7,
+              drop=masks["dropout7"] if masks else None, mask=S["fea"])
         # ---- blocks, last to first trainable
         for i in range(len(arch.BLOCKS) - 1, -1, -1):
             b = arch.BLOCKS[i]
@@ -406,32 +460,29 @@ class Engine:
             if name in arch.FROZEN_BLOCKS:
                 break
             same = arch.block_same_shape(b)
-            ih, iw, oh, ow = S["dims"][name]
+            din, dout = S["dims"][name]
+            Mi = rows_of(din)
+            Mo = rows_of(dout)
             sv = S[name]
             sa, _ = P["bn"][name + ".bn_branch2a"]
             first_trainable = name == "b3"               # its input comes from the frozen prefix
             if kind == "res":
                 s1, _ = P["bn"][name + ".bn_branch2b1"]
-                du = E(N, oh, ow, mid)
-                L.conv_igemm(D, P["wt"][name + ".conv_branch2b1"], du, N=N, IH=oh, IW=ow, IC=cout, OH=oh, OW=ow, OC=mid,
-                             KH=3, KW=3, dil=d, pad=d, mode=1, epi=1, scale=s1, mask=sv["v"])
-                wgrad(name + ".conv_branch2b1", sv["v"], D, N=N, IH=oh, IW=ow, IC=mid, OH=oh, OW=ow, OC=cout, KH=3, KW=3, dil=d, pad=d)
-                wgrad(name + ".conv_branch2a", sv["t"], du, N=N, IH=ih, IW=iw, IC=cin, OH=oh, OW=ow, OC=mid, KH=3, KW=3,
-                      stride=stride, dil=fd, pad=fd)
+                du = E(Mo, mid)
+                dgrad(D, name + ".conv_branch2b1", du, mid, cout, 3, 1, d, dout, dout, epi=1, scale=s1, mask=sv["v"])
+                wgrad(name + ".conv_branch2b1", sv["v"], D, mid, cout, 3, 1, d, dout, dout)
+                wgrad(name + ".conv_branch2a", sv["t"], du, cin, mid, 3, stride, fd, din, dout)
                 if not same:
-                    wgrad(name + ".conv_branch1", sv["t"], D, N=N, IH=ih, IW=iw, IC=cin, OH=oh, OW=ow, OC=cout, KH=1, KW=1, stride=stride)
+                    wgrad(name + ".conv_branch1", sv["t"], D, cin, cout, 1, stride, 1, din, dout)
                 if first_trainable:
                     break
-                Din = E(N, ih, iw, cin)
+                Din = E(Mi, cin)
                 if same:
-                    L.conv_igemm(du, P["wt"][name + ".conv_branch2a"], Din, N=N, IH=oh, IW=ow, IC=mid, OH=ih, OW=iw, OC=cin,
-                                 KH=3, KW=3, stride=stride, dil=fd, pad=fd, mode=1, epi=1, scale=sa, mask=sv["t"], r_post=D)
+                    dgrad(du, name + ".conv_branch2a", Din, cin, mid, 3, stride, fd, din, dout, epi=1, scale=sa, mask=sv["t"], r_post=D)
                 else:
-                    tmp = E(N, ih, iw, cin)
-                    L.conv_igemm(D, P["wt"][name + ".conv_branch1"], tmp, N=N, IH=oh, IW=ow, IC=cout, OH=ih, OW=iw, OC=cin,
-                                 KH=1, KW=1, stride=stride, mode=1)
-                    L.conv_igemm(du, P["wt"][name + ".conv_branch2a"], Din, N=N, IH=oh, IW=ow, IC=mid, OH=ih, OW=iw, OC=cin,
-                                 KH=3, KW=3, stride=stride, dil=fd, pad=fd, mode=1, epi=1, scale=sa, mask=sv["t"], r_pre=tmp)
+                    tmp = E(Mi, cin)
+                    dgrad(D, name + ".conv_branch1", tmp, cin, cout, 1, stride, 1, din, dout)
+                    dgrad(du, name + ".conv_branch2a", Din, cin, mid, 3, stride, fd, din, dout, epi=1, scale=sa, mask=sv["t"], r_pre=tmp)
                 D = Din
             else:
                 c4, c2 = cout // 4, cout // 2
@@ -439,42 +490,34 @@ class Engine:
                 s2, _ = P["bn"][name + ".bn_branch2b2"]
                 d1 = masks[name + ".dropout_2b1"] if masks else None
                 d2 = masks[name + ".dropout_2b2"] if masks else None
-                du2 = E(N, oh, ow, c2)
-                L.conv_igemm(D, P["wt"][name + ".conv_branch2b2"], du2, N=N, IH=oh, IW=ow, IC=cout, OH=oh, OW=ow, OC=c2,
-                             KH=1, KW=1, mode=1, epi=1, scale=s2, drop=d2, mask=sv["v2"])
-                wgrad(name + ".conv_branch2b2", sv["v2"], D, N=N, IH=oh, IW=ow, IC=c2, OH=oh, OW=ow, OC=cout, KH=1, KW=1)
-                du1 = E(N, oh, ow, c4)
-                L.conv_igemm(du2, P["wt"][name + ".conv_branch2b1"], du1, N=N, IH=oh, IW=ow, IC=c2, OH=oh, OW=ow, OC=c4,
-                             KH=3, KW=3, dil=d, pad=d, mode=1, epi=1, scale=s1, drop=d1, mask=sv["v1"])
-                wgrad(name + ".conv_branch2b1", sv["v1"], du2, N=N, IH=oh, IW=ow, IC=c4, OH=oh, OW=ow, OC=c2, KH=3, KW=3, dil=d, pad=d)
-                wgrad(name + ".conv_branch1", sv["t"], D, N=N, IH=ih, IW=iw, IC=cin, OH=oh, OW=ow, OC=cout, KH=1, KW=1, stride=stride)
-                wgrad(name + ".conv_branch2a", sv["t"], du1, N=N, IH=ih, IW=iw, IC=cin, OH=oh, OW=ow, OC=c4, KH=1, KW=1, stride=stride)
-                tmp = E(N, ih, iw, cin)
-                L.conv_igemm(D, P["wt"][name + ".conv_branch1"], tmp, N=N, IH=oh, IW=ow, IC=cout, OH=ih, OW=iw, OC=cin,
-                             KH=1, KW=1, stride=stride, mode=1)
-                Din = E(N, ih, iw, cin)
-                L.conv_igemm(du1, P["wt"][name + ".conv_branch2a"], Din, N=N, IH=oh, IW=ow, IC=c4, OH=ih, OW=iw, OC=cin,
-                             KH=1, KW=1, stride=stride, mode=1, epi=1, scale=sa, mask=sv["t"], r_pre=tmp)
+                du2 = E(Mo, c2)
+                dgrad(D, name + ".conv_branch2b2", du2, c2, cout, 1, 1, 1, dout, dout, epi=1, scale=s2, drop=d2, mask=sv["v2"])
+                wgrad(name + ".conv_branch2b2", sv["v2"], D, c2, cout, 1, 1, 1, dout, dout)
+                du1 = E(Mo, c4)
+                dgrad(du2, name + ".conv_branch2b1", du1, c4, c2, 3, 1, d, dout, dout, epi=1, scale=s1, drop=d1, mask=sv["v1"])
+                wgrad(name + ".conv_branch2b1", sv["v1"], du2, c4, c2, 3, 1, d, dout, dout)
+                wgrad(name + ".conv_branch1", sv["t"], D, cin, cout, 1, stride, 1, din, dout)
+                wgrad(name + ".conv_branch2a", sv["t"], du1, cin, c4, 1, stride, 1, din, dout)
+                tmp = E(Mi, cin)
+                dgrad(D, name + ".conv_branch1", tmp, cin, cout, 1, stride, 1, din, dout)
+                Din = E(Mi, cin)
+                dgrad(du1, name + ".conv_branch2a", Din, cin, c4, 1, stride, 1, din, dout, epi=1, scale=sa, mask=sv["t"], r_pre=tmp)
                 D = Din
 
 
 class _NetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, anchor, eng, lowres):
-        outs, S = eng.run_forward(x, save=True, lowres=lowres)
+        outs, S = eng.run_forward([x], save=True, lowres=lowres)
         ctx.eng, ctx.S = eng, S
         ctx.set_materialize_grads(False)
         if lowres:
-            ctx.mark_non_differentiable(outs[3])
-        return outs
+            ctx.mark_non_differentiable(outs[0][3])
+        return outs[0]
 
     @staticmethod
     def backward(ctx, g0, g1, g2, g3):
         S = ctx.S
-        if S["lowres"]:
-            # outs = (cam_low, rvd, f_proj view, head rows): g2 is d(f_proj) in NCHW-logical layout
-            ctx.eng.run_backward(S, g0, g1, g2, None)
-        else:
-            ctx.eng.run_backward(S, g0, g1, g2, g3)
+        ctx.eng.run_backward(S, [(g0, g1, g2, None if S["lowres"] else g3)])
         ctx.S = None
         return None, None, None, None

@@ -148,15 +148,17 @@ def step(model, img1, img2, label20, bg_threshold=0.20, rng=None, rng_parity=Fal
     main = torch.cuda.current_stream(dev)
     use_streams = os.environ.get("WSEG_STREAMS", "1") != "0"
     side = _side_streams(eng, dev) if use_streams else (main, main)
+    # Both views go through the network in ONE batched pass (two row segments per launch); the per-view map
+    # losses then run on their own HIP streams.
+    outs, ctx = eng.run_forward([img1, img2], save=True, lowres=True)
     fork = main.record_event()
     views = []
-    for img, st in zip((img1, img2), side):
+    for img, (cam_low, rvd, _fp, head), vw, st in zip((img1, img2), outs, ctx["views"], side):
+        v = _View()
+        v.S, v.h, v.w, v.off = img.shape[2], vw["h"], vw["w"], vw["off"]
+        v.cam_low, v.rvd, v.head = cam_low, rvd, head
         st.wait_event(fork)
         with torch.cuda.stream(st):
-            (cam_low, rvd, _fp, head), S = eng.run_forward(img, save=True, lowres=True)
-            v = _View()
-            v.S, v.h, v.w, v.ctx = img.shape[2], S["h"], S["w"], S
-            v.cam_low, v.rvd, v.head = cam_low, rvd, head
             _maps_forward(v, label20, acc, N)
         views.append(v)
     v1, v2 = views
@@ -198,17 +200,11 @@ def step(model, img1, img2, label20, bg_threshold=0.20, rng=None, rng_parity=Fal
         v.dF = _f32(P, 128, dev=dev)
         L.nce_loss_grad(v.fn, v.nrm, v.S_own, v.S_oth, v.y, o.y, v.w_intra, v.protos, o.protos, v.dF, acc[4:7], P,
                         0.1 / (2 * P), 0.05)
-    # ---- into the network (again one stream per view; weight gradients accumulate with atomics)
-    fork = main.record_event()
-    for v, st in zip((v1, v2), side):
-        st.wait_event(fork)
-        with torch.cuda.stream(st):
-            d_head = torch.empty_like(v.head)
-            L.head_grad_fused(v.dF, v.d_cam_low, v.head, d_head, HEAD_LD, N, v.h, v.w, 16, 16)
-            eng.run_backward(v.ctx, None, v.d_rvd, None, None, d_head_rows=d_head)
-            v.ctx = None
-    for st in side:
-        main.wait_stream(st)
+    # ---- into the network: one batched backward over both views
+    d_head = torch.empty_like(ctx["head"])
+    for v in views:
+        L.head_grad_fused(v.dF, v.d_cam_low, v.head, d_head[v.off:], HEAD_LD, N, v.h, v.w, 16, 16)
+    eng.run_backward(ctx, [(None, v.d_rvd, None, None) for v in views], d_head_rows=d_head)
     loss_cls = acc[0] * 0.5 + acc[1]
     loss_er = acc[2] * er_coef
     loss_ecr = acc[3]
