@@ -60,7 +60,8 @@ typedef struct wseg_conv_desc {
   int32_t mode, epi, dtype;
   int32_t relu_out2;   /* 1: out2 gets the ReLU (default); 0: affine only */
   int32_t relu_lt;     /* epi 0: ReLU on `out` channels < relu_lt (fused head: f_proj | cam); 0 = none */
-  int32_t bm_hint;     /* 0 = library chooses the pixel-tile height (64 for few pixels, else 128); 64 / 128 = force */
+  int32_t bm_hint;     /* 0 = library chooses the tile (64 / 128 pixel rows x 128 channels, or the 256 x 256 phase-pipelined
+                          bf16 kernel for large layers with OC % 256 == 0); 64 / 128 / 256 = force */
   /* optional SECOND row segment (the 128x128 view batched behind the 448x448 view in one launch): rows
    * [0, N*OH*OW) use (IH,IW,OH,OW); rows beyond use (IH2,IW2,OH2,OW2), same N, their input pixels follow the
    * first segment's N*IH*IW rows; drop then has 2N rows.  OH2 == 0: single segment. */
@@ -163,7 +164,8 @@ int wseg_pcm_backward_bf16(const void* Fb, const void* Gb, const float* d_cam_rv
  *  intra_weights      hard-pixel sampling: random half + similarity rank band per class (:302-331)
  *  nce_loss_grad      cross-prototype, cross-pseudo-label and intra-view InfoNCE + gradient w.r.t. the features (:261-334)
  */
-int wseg_plane_stats(const float* U, float* stats, long planes, int npix, void* stream);
+size_t wseg_plane_stats_workspace_bytes(long planes);
+int wseg_plane_stats(const float* U, float* stats, long planes, int npix, void* workspace, void* stream);
 int wseg_cls_loss(const float* stats, const float* label20, float* loss_out, float* plane_bias, int N, int npix, float coef, void* stream);
 int wseg_rvmin_values(const float* U, const float* label20, float* q, unsigned char* argc, int N, int npix, void* stream);
 size_t wseg_select_workspace_bytes(int rows);

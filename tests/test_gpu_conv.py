@@ -81,12 +81,13 @@ def test_conv_fwd_dgrad_wgrad(case, dt, bm):
     assert np.abs(dwg.cpu().numpy() - 2 * ref).max() / scale < 2 * wtol
 
 
-@pytest.mark.parametrize("dt", ["f32", "bf16"])
-def test_conv_epilogues(dt):
-    """fused BN-ReLU-dropout second output (forward) and masked-scale (+residual) epilogue (backward)."""
+@pytest.mark.parametrize("dt,OC,bm", [("f32", 128, 0), ("bf16", 128, 0), ("bf16", 256, 256)])
+def test_conv_epilogues(dt, OC, bm):
+    """fused BN-ReLU-dropout second output (forward) and masked-scale (+residual) epilogue (backward);
+    bm=256: the 256x256 phase-pipelined kernel (300 rows = one full + one partial row tile)."""
     from wseg_amd import _lib as L
     tdt = torch.float32 if dt == "f32" else torch.bfloat16
-    N, H, W, IC, OC, k = 2, 12, 10, 64, 128, 3
+    N, H, W, IC, k = 2, 15, 10, 64, 3
     dev = "cuda"
     x = _rand((N, IC, H, W), 1).to(tdt).float()
     w = _rand((OC, IC, k, k), 2, 0.06).to(tdt).float()
@@ -103,7 +104,7 @@ def test_conv_epilogues(dt):
     out2 = torch.empty(N, H, W, OC, device=dev, dtype=tdt)
     L.conv_igemm(xg, wf, out, out2, N=N, IH=H, IW=W, IC=IC, OH=H, OW=W, OC=OC, KH=k, KW=k, pad=1,
                  r_pre=_nhwc(pre).to(dev, tdt), r_post=_nhwc(res).to(dev, tdt),
-                 scale=scale.to(dev), shift=shift.to(dev), drop=drop.to(dev))
+                 scale=scale.to(dev), shift=shift.to(dev), drop=drop.to(dev), bm_hint=bm)
     tol = dict(rtol=2e-5, atol=2e-5) if dt == "f32" else dict(rtol=2e-2, atol=3e-2)
     np.testing.assert_allclose(out.float().cpu().numpy(), _nhwc(raw).numpy(), **tol)
     # out2 is computed from the unrounded sum in-kernel; compare loosely in bf16
@@ -113,13 +114,14 @@ def test_conv_epilogues(dt):
     exp = (y + pre) * scale.view(1, -1, 1, 1) * drop.view(N, OC, 1, 1) * (mask > 0).float() + res
     L.conv_igemm(xg, wf, out, N=N, IH=H, IW=W, IC=IC, OH=H, OW=W, OC=OC, KH=k, KW=k, pad=1, epi=1,
                  r_pre=_nhwc(pre).to(dev, tdt), r_post=_nhwc(res).to(dev, tdt), mask=_nhwc(mask).to(dev, tdt),
-                 scale=scale.to(dev), drop=drop.to(dev))
+                 scale=scale.to(dev), drop=drop.to(dev), bm_hint=bm)
     np.testing.assert_allclose(out.float().cpu().numpy(), _nhwc(exp).numpy(), **tol)
     # epi 2 with an output row stride and channel offset (writes into a wider buffer)
-    wide = torch.zeros(N, H, W, 256, device=dev, dtype=tdt)
-    L.conv_igemm(xg, wf, wide[..., 64:], N=N, IH=H, IW=W, IC=IC, OH=H, OW=W, OC=OC, KH=k, KW=k, pad=1, epi=2, ld_out=256)
-    np.testing.assert_allclose(wide[..., 64:192].float().cpu().numpy(), _nhwc(F.relu(y)).numpy(), **tol)
-    assert float(wide[..., :64].abs().max()) == 0 and float(wide[..., 192:].abs().max()) == 0
+    wide = torch.zeros(N, H, W, OC + 128, device=dev, dtype=tdt)
+    L.conv_igemm(xg, wf, wide[..., 64:], N=N, IH=H, IW=W, IC=IC, OH=H, OW=W, OC=OC, KH=k, KW=k, pad=1, epi=2, ld_out=OC + 128,
+                 bm_hint=bm)
+    np.testing.assert_allclose(wide[..., 64:64 + OC].float().cpu().numpy(), _nhwc(F.relu(y)).numpy(), **tol)
+    assert float(wide[..., :64].abs().max()) == 0 and float(wide[..., 64 + OC:].abs().max()) == 0
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
@@ -160,14 +162,14 @@ def test_conv_many_row_tiles(dt):
     np.testing.assert_allclose(yg.float().cpu().numpy(), _nhwc(y).numpy(), **tol)
 
 
-@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("dt,bm", [("f32", 0), ("bf16", 0), ("bf16", 256)])
 @pytest.mark.parametrize("geom", [(3, 1, 2), (3, 2, 1), (1, 2, 1)])
-def test_conv_two_row_segments(dt, geom):
+def test_conv_two_row_segments(dt, bm, geom):
     """Two views batched in one launch: rows [0,N*OH*OW) use geometry 1, the rest geometry 2 (fwd, dgrad, wgrad)."""
     from wseg_amd import _lib as L
     k, s, d = geom
     tdt = torch.float32 if dt == "f32" else torch.bfloat16
-    N, IC, OC = 2, 64, 256
+    N, IC, OC = 2, (256 if bm == 256 else 64), 256      # bm=256: dgrad (OC = IC) takes the 256-tile kernel too
     (H1, W1), (H2, W2) = (20, 18), (9, 11)
     pad = d * (k // 2)
     osz = lambda h: (h + 2 * pad - d * (k - 1) - 1) // s + 1
@@ -186,12 +188,12 @@ def test_conv_two_row_segments(dt, geom):
     O1, O2 = (osz(H1), osz(W1)), (osz(H2), osz(W2))
     seg_f = (H2, W2, O2[0], O2[1])
     yg = torch.empty(dyj.shape[0], OC, device=dev, dtype=tdt)
-    L.conv_igemm(xj, wf, yg, N=N, IH=H1, IW=W1, IC=IC, OH=O1[0], OW=O1[1], OC=OC, KH=k, KW=k, stride=s, dil=d, pad=pad, seg2=seg_f)
+    L.conv_igemm(xj, wf, yg, N=N, IH=H1, IW=W1, IC=IC, OH=O1[0], OW=O1[1], OC=OC, KH=k, KW=k, stride=s, dil=d, pad=pad, seg2=seg_f, bm_hint=bm)
     tol = dict(rtol=2e-5, atol=2e-5) if dt == "f32" else dict(rtol=2e-2, atol=2e-2)
     np.testing.assert_allclose(yg.float().cpu().numpy(), torch.cat([rows(y.detach()) for y in ys]).numpy(), **tol)
     dxg = torch.empty(xj.shape[0], IC, device=dev, dtype=tdt)
     L.conv_igemm(dyj, wt, dxg, N=N, IH=O1[0], IW=O1[1], IC=OC, OH=H1, OW=W1, OC=IC, KH=k, KW=k, stride=s, dil=d, pad=pad, mode=1,
-                 seg2=(O2[0], O2[1], H2, W2))
+                 seg2=(O2[0], O2[1], H2, W2), bm_hint=bm)
     np.testing.assert_allclose(dxg.float().cpu().numpy(), torch.cat([rows(x.grad) for x in xs]).numpy(), **tol)
     ref = w.grad.permute(0, 2, 3, 1).reshape(OC, k * k, IC).numpy()
     for hint in (128, 256):
@@ -199,3 +201,48 @@ def test_conv_two_row_segments(dt, geom):
         L.conv_wgrad(xj, dyj, dwg, N=N, IH=H1, IW=W1, IC=IC, OH=O1[0], OW=O1[1], OC=OC, KH=k, KW=k, stride=s, dil=d, pad=pad,
                      seg2=seg_f, tile_hint=hint, split_k=2)
         assert np.abs(dwg.cpu().numpy() - ref).max() / np.abs(ref).max() < (2e-5 if dt == "f32" else 1e-2)
+
+
+CASES256 = [
+    # N, H, W, IC, OC, k, stride, dil      (bf16, OC % 256 == 0: the 256x256 phase-pipelined kernel)
+    (2, 20, 19, 128, 512, 3, 1, 2),      # 760 rows: 2 full + 1 partial row tile, 2 column tiles, 18 K-tiles
+    (1, 33, 31, 256, 256, 3, 2, 1),      # stride 2 (dgrad with inexact divisions), dgrad through the same kernel
+    (2, 16, 16, 192, 256, 1, 1, 1),      # 1x1, 3 K-tiles per tap
+    (2, 17, 15, 64, 256, 1, 2, 1),       # 1x1 stride 2, ONE K-tile (prologue-only pipeline)
+    (1, 12, 12, 64, 256, 3, 1, 4),       # dilation 4 on a small map: most taps are padding
+    (3, 9, 9, 128, 768, 3, 1, 1),        # 243 rows (< one tile), 3 column tiles
+]
+
+
+@pytest.mark.parametrize("case", CASES256)
+def test_conv256_fwd_dgrad(case):
+    from wseg_amd import _lib as L
+    N, H, W, IC, OC, k, s, d = case
+    tdt = torch.bfloat16
+    pad = d * (k // 2)
+    OH = (H + 2 * pad - d * (k - 1) - 1) // s + 1
+    OW = (W + 2 * pad - d * (k - 1) - 1) // s + 1
+    x = _rand((N, IC, H, W), 1).to(tdt).float().requires_grad_(True)
+    w = _rand((OC, IC, k, k), 2, (2.0 / (IC * k * k)) ** 0.5).to(tdt).float().requires_grad_(True)
+    dy = _rand((N, OC, OH, OW), 3).to(tdt).float()
+    y = F.conv2d(x, w, None, s, pad, d)
+    y.backward(dy)
+    dev = "cuda"
+    xg = _nhwc(x.detach()).to(dev, tdt)
+    wm = w.detach().permute(0, 2, 3, 1).contiguous().to(dev)
+    wf = torch.empty(OC, k * k, IC, device=dev, dtype=tdt)
+    wt = torch.empty(IC, k * k, OC, device=dev, dtype=tdt)
+    L.pack_weights(wm, wf, wt, OC, k * k, IC, OC, IC, L.dtype_code(wf))
+    tol = dict(rtol=2e-2, atol=2e-2)
+    yg = torch.empty(N, OH, OW, OC, device=dev, dtype=tdt)
+    L.conv_igemm(xg, wf, yg, N=N, IH=H, IW=W, IC=IC, OH=OH, OW=OW, OC=OC, KH=k, KW=k, stride=s, dil=d, pad=pad, bm_hint=256)
+    np.testing.assert_allclose(yg.float().cpu().numpy(), _nhwc(y.detach()).numpy(), **tol)
+    # the two tile geometries must agree to accumulation-order noise
+    y128 = torch.empty_like(yg)
+    L.conv_igemm(xg, wf, y128, N=N, IH=H, IW=W, IC=IC, OH=OH, OW=OW, OC=OC, KH=k, KW=k, stride=s, dil=d, pad=pad, bm_hint=128)
+    assert float((yg.float() - y128.float()).abs().max()) <= 2e-2
+    if IC % 256 == 0:                     # dgrad: the conv's IC is the GEMM's N
+        dxg = torch.empty(N, H, W, IC, device=dev, dtype=tdt)
+        L.conv_igemm(_nhwc(dy).to(dev, tdt), wt, dxg, N=N, IH=OH, IW=OW, IC=OC, OH=H, OW=W, OC=IC, KH=k, KW=k, stride=s, dil=d,
+                     pad=pad, mode=1, bm_hint=256)
+        np.testing.assert_allclose(dxg.float().cpu().numpy(), _nhwc(x.grad).numpy(), **tol)

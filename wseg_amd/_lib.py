@@ -210,7 +210,12 @@ def _f(x):
     return C.c_float(x)
 
 
-def plane_stats(U, stats, planes, npix): _call("wseg_plane_stats", _v(U), _v(stats), C.c_long(planes), npix)
+lib.wseg_plane_stats_workspace_bytes.restype = C.c_size_t
+
+
+def plane_stats(U, stats, planes, npix):
+    ws = torch.empty(int(lib.wseg_plane_stats_workspace_bytes(C.c_long(planes))), device=U.device, dtype=torch.uint8)
+    _call("wseg_plane_stats", _v(U), _v(stats), C.c_long(planes), npix, _v(ws))
 def cls_loss(stats, label20, loss_out, plane_bias, N, npix, coef): _call("wseg_cls_loss", _v(stats), _v(label20), _v(loss_out), _v(plane_bias), N, npix, _f(coef))
 def rvmin_values(U, label20, q, argc, N, npix): _call("wseg_rvmin_values", _v(U), _v(label20), _v(q), _v(argc), N, npix)
 def select_workspace_bytes(rows): return int(lib.wseg_select_workspace_bytes(rows))

@@ -10,6 +10,7 @@
 // f32 (parity mode): v_mfma_f32_16x16x4_f32 (bit-exact f32 fma chain).
 // LDS rows are XOR-swizzled at 16-B granularity (phys = chunk ^ ((row>>1)&7)) — applied on the
 // DMA source side and on the ds_read side (the LDS image itself stays lane-linear).
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -27,6 +28,118 @@ struct Args {
   int nwg;
   int row0;         // first output row (pixel) of this launch (a launch may cover a row sub-range)
 };
+
+// Per-thread BN scale / shift of its 8-channel column group (1 / 0 when absent).
+__device__ __forceinline__ void epilogue_coeffs(const wseg_conv_desc& d, int n0, int cv, float (&sc)[8], float (&sh)[8]) {
+  const int oc_raw = n0 + cv;
+  const int oc = oc_raw < d.OC ? oc_raw : 0;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { sc[e] = 1.f; sh[e] = 0.f; }
+  if (d.scale != nullptr) load8<WSEG_F32>(d.scale, oc, sc);
+  if (d.shift != nullptr) load8<WSEG_F32>(d.shift, oc, sh);
+}
+
+// Fused epilogue over an f32 LDS image of ROWS x COLS accumulators (row stride LD floats), NT threads.
+// Every thread owns ONE 8-channel column group.  All global operands of a chunk of rows are loaded before
+// any of them is consumed: one memory round trip per chunk instead of one per row (the dependent-load
+// chain was the whole cost of short-K layers).  Rows beyond M are clamped to row 0 for the loads and
+// predicated off at the stores (no divergent control flow).
+template <int DT, int EPI, int ROWS, int COLS, int LD, int NT, int MAXCHK = 4>
+__device__ __forceinline__ void epilogue_image(const wseg_conv_desc& d, int M, const float* img, int m0, int n0, int tid,
+                                               const float (&sc)[8], const float (&sh)[8]) {
+  constexpr int GPR = COLS / 8;                    // column groups per row
+  constexpr int RPS = NT / GPR;                    // rows per sweep of the workgroup
+  constexpr int SWEEPS = ROWS / RPS;
+  constexpr int CHK = SWEEPS < MAXCHK ? SWEEPS : MAXCHK;
+  static_assert(NT % GPR == 0 && ROWS % RPS == 0 && SWEEPS % CHK == 0, "epilogue geometry");
+  const int cv = (tid % GPR) * 8;
+  const int oc_raw = n0 + cv;
+  const bool col_ok = oc_raw < d.OC;                        // OC is a multiple of 8 (host-checked)
+  const int oc = col_ok ? oc_raw : 0;
+  const bool has_pre = d.r_pre != nullptr, has_post = d.r_post != nullptr, has_mask = d.mask != nullptr;
+  const bool has_drop = d.drop != nullptr;
+#pragma unroll 1
+  for (int c0 = 0; c0 < SWEEPS; c0 += CHK) {
+    float rpre[CHK][8], rpost[CHK][8], mk[CHK][8], dr[CHK][8];
+    size_t mrow[CHK];
+    bool ok[CHK];
+#pragma unroll
+    for (int j = 0; j < CHK; ++j) {
+      const int row = ((c0 + j) * NT + tid) / GPR;
+      ok[j] = col_ok && (m0 + row) < M;
+      mrow[j] = ok[j] ? (size_t)(m0 + row) : 0;
+    }
+    if (has_pre) {
+#pragma unroll
+      for (int j = 0; j < CHK; ++j) load8<DT>(d.r_pre, mrow[j] * d.ld_rpre + oc, rpre[j]);
+    }
+    if (has_post) {
+#pragma unroll
+      for (int j = 0; j < CHK; ++j) load8<DT>(d.r_post, mrow[j] * d.ld_rpost + oc, rpost[j]);
+    }
+    if (EPI == 1 && has_mask) {
+#pragma unroll
+      for (int j = 0; j < CHK; ++j) load8<DT>(d.mask, mrow[j] * d.ld_mask + oc, mk[j]);
+    }
+    if (EPI != 2 && has_drop) {
+#pragma unroll
+      for (int j = 0; j < CHK; ++j) load8<WSEG_F32>(d.drop, (size_t)wseg_decode_row(d, (int)mrow[j]).n_glob * d.OC + oc, dr[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < CHK; ++j) {
+      const int row = ((c0 + j) * NT + tid) / GPR;
+      const size_t m = mrow[j];
+      float v[8];
+      {
+        const f32x4 p0 = *reinterpret_cast<const f32x4*>(&img[row * LD + cv]);
+        const f32x4 p1 = *reinterpret_cast<const f32x4*>(&img[row * LD + cv + 4]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = p0[e]; v[4 + e] = p1[e]; }
+      }
+      if (has_pre) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += rpre[j][e];
+      }
+      if constexpr (EPI == 0) {
+        if (has_post) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += rpost[j][e];
+        }
+        if (d.relu_lt > 0) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) if (oc + e < d.relu_lt) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (d.out != nullptr && ok[j]) store8<DT>(d.out, m * d.ld_out + oc, v);
+        if (d.out2 != nullptr) {
+          float t[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float x = v[e] * sc[e] + sh[e];
+            if (d.relu_out2) x = fmaxf(x, 0.f);
+            if (has_drop) x *= dr[j][e];
+            t[e] = x;
+          }
+          if (ok[j]) store8<DT>(d.out2, m * d.ld_out2 + oc, t);
+        }
+      } else if constexpr (EPI == 1) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float x = v[e] * sc[e];
+          if (has_drop) x *= dr[j][e];
+          if (has_mask) x = mk[j][e] > 0.f ? x : 0.f;
+          if (has_post) x += rpost[j][e];
+          o[e] = x;
+        }
+        if (ok[j]) store8<DT>(d.out, m * d.ld_out + oc, o);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        if (ok[j]) store8<DT>(d.out, m * d.ld_out + oc, v);
+      }
+    }
+  }
+}
 
 // BM = 128 (default) or 64 (few output pixels: twice the workgroups for the same work)
 template <int DT, int EPI, int BM>
@@ -197,102 +310,198 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const Args a) {
     }
   __syncthreads();
 
-  // Every thread owns ONE 8-channel column group of 8 rows.  All global operands of a chunk of rows
-  // are loaded before any of them is consumed: one memory round trip per chunk instead of one per row
-  // (the dependent-load chain was the whole cost of short-K layers).  Rows beyond M are clamped to
-  // row 0 for the loads and predicated off at the stores (no divergent control flow).
-  const int cv = (tid & 15) * 8;
-  const int oc_raw = n0 + cv;
-  const bool col_ok = oc_raw < d.OC;                        // OC is a multiple of 8 (host-checked)
-  const int oc = col_ok ? oc_raw : 0;
-  const bool has_pre = d.r_pre != nullptr, has_post = d.r_post != nullptr, has_mask = d.mask != nullptr;
-  const bool has_drop = d.drop != nullptr, has_scale = d.scale != nullptr, has_shift = d.shift != nullptr;
   float sc[8], sh[8];
+  epilogue_coeffs(d, n0, (tid & 15) * 8, sc, sh);
+  epilogue_image<DT, EPI, BM, BN, EPI_LD, 256>(d, a.M, img, m0, n0, tid, sc, sh);
+}
+
+// ---- 256 x 256 bf16 phase-pipelined variant (large layers) ------------------------------------------------
+// The 128^2 kernel above fills a CU at the L2->LDS rate with 64 FLOP per filled byte (a ~1.1 PF ceiling); a
+// 256x256 tile doubles that.  Schedule (validated on plain GEMM in csrc/gemm256_probe.hip, in production for
+// wgrad): 8 waves as 2(M) x 4(N), wave tile 128 x 64 = 8 x 4 accumulators; LDS = 2 K-tiles x 4 half-tile slots
+// {A0, A1, B0, B1}, each [128 rows][128 B] = 16 KiB.  A K-tile (one 128-B slice of one tap) is 4 phases of 16
+// MFMAs (one 64 x 32 quadrant of the wave tile); every phase refills ONE slot that all waves have finished
+// reading:    p1(u): A0(u+1)   p2(u): A1(u+1)   p3(u): B0(u+2)   p4(u): B1(u+2)
+// so LDS-DMA runs 1.5 tiles ahead with two tile buffers; the only DMA wait is ONE counted s_waitcnt vmcnt(4)
+// per K-tile (B0/B1(u+2) stay in flight) and one raw s_barrier per phase.  The im2col gather is again only the
+// per-lane source address (4 pixel rows per thread, re-derived once per tap); padded taps read the zero page.
+// Epilogue: 4 passes of 64 rows through a 65-KiB f32 LDS image, same fused epilogue as the 128^2 kernel.
+constexpr int HALF256 = 16384, TILE256 = 4 * HALF256, EPI_LD256 = 256 + 4;
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const Args a) {
+  constexpr int DT = WSEG_BF16, ES = 2, CH = 8;
+  __shared__ __attribute__((aligned(16))) char smem[2 * TILE256];
+  const wseg_conv_desc& d = a.d;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tile = xcd_remap(blockIdx.x, a.nwg);
+  const int tm = tile / a.ntn, tn = tile - tm * a.ntn;
+  const int m0 = a.row0 + tm * 256, n0 = tn * 256;
+  const int wr = wid >> 2, wc = wid & 3;
+  const int frow = lane & 15, fk = lane >> 4, sw = (lane >> 1) & 7;
+
+  const char* zero = reinterpret_cast<const char*>(g_wseg_zero_page);
+  const char* IN = reinterpret_cast<const char*>(d.in);
+  const char* Wp = reinterpret_cast<const char*>(d.w);
+
+  // ---- staging: thread -> rows r0 + 64*j (j = 0..3) of the A tile and of the B tile, physical chunk tid&7.
+  //      ((row>>1)&7 is the same for all four rows, so one logical chunk per thread.)  Per-row state is kept
+  //      small (the accumulators + fragments already take 192 of the 256 registers): a 32-bit first-input-row
+  //      (or -1 beyond M) and one packed word {segment | iy0 | ix0}; B rows are a uniform stride apart.
+  const int r0 = tid >> 3, pch = tid & 7;
+  const int lc = pch ^ ((r0 >> 1) & 7);
+  const char* zsrc = zero + pch * 16;
+  const char* INl = IN + lc * 16;
+  int a_base[4], a_yx[4];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) { sc[e] = 1.f; sh[e] = 0.f; }
-  if (has_scale) load8<WSEG_F32>(d.scale, oc, sc);
-  if (has_shift) load8<WSEG_F32>(d.shift, oc, sh);
-  constexpr int CHK = 4;
-#pragma unroll 1
-  for (int c0 = 0; c0 < BM / 16; c0 += CHK) {
-    float rpre[CHK][8], rpost[CHK][8], mk[CHK][8], dr[CHK][8];
-    size_t mrow[CHK];
-    bool ok[CHK];
-#pragma unroll
-    for (int j = 0; j < CHK; ++j) {
-      const int row = ((c0 + j) * 256 + tid) >> 4;
-      ok[j] = col_ok && (m0 + row) < a.M;
-      mrow[j] = ok[j] ? (size_t)(m0 + row) : 0;
+  for (int j = 0; j < 4; ++j) {
+    const int m = m0 + r0 + 64 * j;
+    if (m < a.M) {
+      const wseg_rowgeo rg = wseg_decode_row(d, m);
+      int iy0, ix0;
+      if (d.mode == 0) { iy0 = rg.oy * d.stride - d.pad; ix0 = rg.ox * d.stride - d.pad; }
+      else             { iy0 = rg.oy + d.pad;            ix0 = rg.ox + d.pad; }
+      a_base[j] = (int)rg.in_base;
+      a_yx[j] = (rg.n_glob >= d.N ? (int)0x80000000 : 0) | ((iy0 + 0x2000) << 16) | (ix0 + 0x2000);
+    } else {
+      a_base[j] = -1; a_yx[j] = (0x2000 << 16) | 0x2000;
     }
-    if (has_pre) {
+  }
+  const char* aptr[4];
+  unsigned a_live = 0;                             // bit j: row j reads real data (pointer advances by 128 B per K-tile)
+  const char* bptr = Wp + ((size_t)(n0 + r0) * a.taps * d.IC + (size_t)lc * CH) * ES;   // OC % 256 == 0 (host-checked)
+  const int brs = 64 * a.taps * d.IC * ES;         // bytes between B rows r0 + 64*j
+  auto set_tap = [&](int tap) {
+    const int ky = tap / d.KW, kx = tap - ky * d.KW;
+    a_live = 0;
 #pragma unroll
-      for (int j = 0; j < CHK; ++j) load8<DT>(d.r_pre, mrow[j] * d.ld_rpre + oc, rpre[j]);
-    }
-    if (has_post) {
-#pragma unroll
-      for (int j = 0; j < CHK; ++j) load8<DT>(d.r_post, mrow[j] * d.ld_rpost + oc, rpost[j]);
-    }
-    if (EPI == 1 && has_mask) {
-#pragma unroll
-      for (int j = 0; j < CHK; ++j) load8<DT>(d.mask, mrow[j] * d.ld_mask + oc, mk[j]);
-    }
-    if (EPI != 2 && has_drop) {
-#pragma unroll
-      for (int j = 0; j < CHK; ++j) load8<WSEG_F32>(d.drop, (size_t)wseg_decode_row(d, (int)mrow[j]).n_glob * d.OC + oc, dr[j]);
-    }
-#pragma unroll
-    for (int j = 0; j < CHK; ++j) {
-      const int row = ((c0 + j) * 256 + tid) >> 4;
-      const size_t m = mrow[j];
-      float v[8];
-      {
-        const f32x4 p0 = *reinterpret_cast<const f32x4*>(&img[row * EPI_LD + cv]);
-        const f32x4 p1 = *reinterpret_cast<const f32x4*>(&img[row * EPI_LD + cv + 4]);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] = p0[e]; v[4 + e] = p1[e]; }
-      }
-      if (has_pre) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += rpre[j][e];
-      }
-      if constexpr (EPI == 0) {
-        if (has_post) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += rpost[j][e];
-        }
-        if (d.relu_lt > 0) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) if (oc + e < d.relu_lt) v[e] = fmaxf(v[e], 0.f);
-        }
-        if (d.out != nullptr && ok[j]) store8<DT>(d.out, m * d.ld_out + oc, v);
-        if (d.out2 != nullptr) {
-          float t[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            float x = v[e] * sc[e] + sh[e];
-            if (d.relu_out2) x = fmaxf(x, 0.f);
-            if (has_drop) x *= dr[j][e];
-            t[e] = x;
-          }
-          if (ok[j]) store8<DT>(d.out2, m * d.ld_out2 + oc, t);
-        }
-      } else if constexpr (EPI == 1) {
-        float o[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float x = v[e] * sc[e];
-          if (has_drop) x *= dr[j][e];
-          if (has_mask) x = mk[j][e] > 0.f ? x : 0.f;
-          if (has_post) x += rpost[j][e];
-          o[e] = x;
-        }
-        if (ok[j]) store8<DT>(d.out, m * d.ld_out + oc, o);
+    for (int j = 0; j < 4; ++j) {
+      const int iy0 = ((a_yx[j] >> 16) & 0x7FFF) - 0x2000, ix0 = (a_yx[j] & 0xFFFF) - 0x2000;
+      const bool s2 = a_yx[j] < 0;
+      const int H = s2 ? d.IH2 : d.IH, W = s2 ? d.IW2 : d.IW;
+      int iy, ix; bool ok = a_base[j] >= 0;
+      if (d.mode == 0) {
+        iy = iy0 + ky * d.dil; ix = ix0 + kx * d.dil;
       } else {
+        const int ty = iy0 - ky * d.dil, tx = ix0 - kx * d.dil;
+        ok = ok && ty >= 0 && tx >= 0;
+        if (d.stride == 1) { iy = ty; ix = tx; }
+        else { iy = ty / d.stride; ix = tx / d.stride; ok = ok && (iy * d.stride == ty) && (ix * d.stride == tx); }
+      }
+      ok = ok && iy >= 0 && iy < H && ix >= 0 && ix < W;
+      if (ok) { aptr[j] = INl + (size_t)(a_base[j] + iy * W + ix) * d.ld_in * ES; a_live |= 1u << j; }
+      else    { aptr[j] = zsrc; }
+    }
+  };
+  int a_tap = 0, a_cc = 0;                         // position of the NEXT A tile to issue
+  auto issue_a = [&](int h, int buf) {             // half h = rows [128h, 128h+128): this thread's rows 2h, 2h+1
+    char* dst = smem + buf * TILE256 + h * HALF256 + wid * 1024;
+    glds16(aptr[2 * h], dst);
+    glds16(aptr[2 * h + 1], dst + 8192);
+  };
+  auto advance_a = [&]() {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-        if (ok[j]) store8<DT>(d.out, m * d.ld_out + oc, v);
+    for (int j = 0; j < 4; ++j) aptr[j] += ((a_live >> j) & 1u) << 7;
+    if (++a_cc == a.cpt) { a_cc = 0; if (++a_tap < a.taps) set_tap(a_tap); }
+  };
+  auto issue_b = [&](int h, int buf) {
+    char* dst = smem + buf * TILE256 + (2 + h) * HALF256 + wid * 1024;
+    glds16(bptr + (2 * h) * brs, dst);
+    glds16(bptr + (2 * h + 1) * brs, dst + 8192);
+  };
+  auto advance_b = [&]() { bptr += 128; };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nt = a.taps * a.cpt;
+  // prologue: tile 0 entirely + the B halves of tile 1 (what p3/p4 of a "tile -1" would have issued)
+  set_tap(0);
+  issue_a(0, 0); issue_a(1, 0); advance_a();
+  issue_b(0, 0); issue_b(1, 0); advance_b();
+  if (nt > 1) { issue_b(0, 1); issue_b(1, 1); advance_b(); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  bf16x8 af[2][4], b0[2][2], b1[2][2];             // [ks][tile]: A sub-tile (64 rows), B sub-tiles hb = 0 / 1 (32 cols each)
+  auto ldA = [&](const char* aH, int ha) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        af[ks][i] = *reinterpret_cast<const bf16x8*>(aH + (ha * 64 + i * 16 + frow) * 128 + (((ks * 4 + fk) ^ sw) << 4));
+  };
+  auto ldB = [&](const char* bH, int hb, bf16x8 (&bf)[2][2]) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        bf[ks][j] = *reinterpret_cast<const bf16x8*>(bH + ((wc & 1) * 64 + hb * 32 + j * 16 + frow) * 128 + (((ks * 4 + fk) ^ sw) << 4));
+  };
+#define MFMA_Q(HA, HB, BF)                                                                                   \
+  do {                                                                                                       \
+    __builtin_amdgcn_s_setprio(1);                                                                           \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                         \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                          \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                        \
+          acc[(HA) * 4 + i][(HB) * 2 + j] =                                                                  \
+              __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][i], BF[ks][j], acc[(HA) * 4 + i][(HB) * 2 + j], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                           \
+  } while (0)
+
+  for (int u = 0; u < nt; ++u) {
+    const int b = u & 1;
+    const char* aH = smem + b * TILE256 + wr * HALF256;
+    const char* bH = smem + b * TILE256 + (2 + (wc >> 1)) * HALF256;
+    // ---- p1: quadrant (0,0)
+    ldA(aH, 0); ldB(bH, 0, b0);
+    if (u + 1 < nt) issue_a(0, b ^ 1);
+    MFMA_Q(0, 0, b0);
+    __builtin_amdgcn_s_barrier();
+    // ---- p2: quadrant (0,1)
+    ldB(bH, 1, b1);
+    if (u + 1 < nt) { issue_a(1, b ^ 1); advance_a(); }
+    MFMA_Q(0, 1, b1);
+    __builtin_amdgcn_s_barrier();
+    // ---- p3: quadrant (1,1)
+    ldA(aH, 1);
+    if (u + 2 < nt) issue_b(0, b);
+    MFMA_Q(1, 1, b1);
+    __builtin_amdgcn_s_barrier();
+    // ---- p4: quadrant (1,0); the counted wait publishes tile u+1 (only B0/B1(u+2) may stay in flight)
+    if (u + 2 < nt) { issue_b(1, b); advance_b(); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MFMA_Q(1, 0, b0);
+    __builtin_amdgcn_s_barrier();
+  }
+#undef MFMA_Q
+
+  // ---- epilogue: 4 passes of 64 rows: accumulators -> LDS f32 image -> coalesced 8-channel vectors
+  float* img = reinterpret_cast<float*>(smem);
+  float sc[8], sh[8];
+  epilogue_coeffs(d, n0, (tid & 31) * 8, sc, sh);
+#pragma unroll
+  for (int ps = 0; ps < 4; ++ps) {
+    if (wr == (ps >> 1)) {
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii) {
+        const int i = (ps & 1) * 4 + ii;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int row = ii * 16 + fk * 4;               // C/D: col = lane&15, row = (lane>>4)*4 + reg
+          const int col = wc * 64 + j * 16 + frow;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) img[(row + e) * EPI_LD256 + col] = acc[i][j][e];
+        }
       }
     }
+    __syncthreads();
+    epilogue_image<DT, EPI, 64, 256, EPI_LD256, 512, 2>(d, a.M, img, m0 + ps * 64, n0, tid, sc, sh);
+    __syncthreads();
   }
 }
 
@@ -337,7 +546,24 @@ extern "C" int wseg_conv_igemm(const wseg_conv_desc* d, void* stream) {
     }                                                                                                           \
   } while (0)
   a.row0 = 0;
-  if (small) {
+  // 256x256 phase-pipelined tiles (bf16, OC >= 256): chosen when the (1 workgroup / CU) rounds are full enough
+  bool big = false;
+  if (d->dtype == WSEG_BF16 && d->OC % 256 == 0 && d->bm_hint != 64 && d->bm_hint != 128 && d->bm_hint >= 0) {
+    const long t256 = ((M + 255) / 256) * ((d->OC + 255) / 256);
+    const long rounds = (t256 + 255) / 256;
+    static const int auto256 = getenv("WSEG_CONV256") ? atoi(getenv("WSEG_CONV256")) : 0;
+    big = d->bm_hint == 256 || (auto256 && t256 >= 200 && (double)t256 / (double)(rounds * 256) >= 0.80);
+    if (big)
+      WSEG_CHECK(d->IH <= 16384 && d->IW <= 16384 && d->OH <= 16384 && d->OW <= 16384 && d->pad <= 4096 &&
+                 (long)d->N * d->IH * d->IW + (long)d->N * d->IH2 * d->IW2 < (1L << 31), "conv_igemm: shape too large for the 256-tile kernel");
+  }
+  if (big) {
+    a.ntn = (d->OC + 255) / 256;
+    a.nwg = (int)(((M + 255) / 256) * a.ntn);
+    if (d->epi == 0) hipLaunchKernelGGL(conv_igemm256_kernel<0>, dim3(a.nwg), dim3(512), 0, s, a);
+    else if (d->epi == 1) hipLaunchKernelGGL(conv_igemm256_kernel<1>, dim3(a.nwg), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL(conv_igemm256_kernel<2>, dim3(a.nwg), dim3(512), 0, s, a);
+  } else if (small) {
     a.nwg = (int)(((M + 63) / 64) * a.ntn);
     WSEG_LAUNCH_CONV(64);
   } else {

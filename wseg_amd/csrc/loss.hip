@@ -32,34 +32,46 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 
 // ---- per-plane statistics of U [planes][npix]: max/min of relu(U) with their first index, sum of U
 //      stats[pl] = {mx, mn, sum, (float)argmax, (float)argmin, 0}
-__global__ __launch_bounds__(256) void plane_stats_kernel(const float* __restrict__ U, float* __restrict__ stats, int npix) {
-  __shared__ float s_mx[256], s_mn[256], s_sum[256];
-  __shared__ int s_imx[256], s_imn[256];
-  const int pl = blockIdx.x, tid = threadIdx.x;
+// A plane is split over `chunks` workgroups; partials meet in packed 64-bit atomics:
+//   max key = (bits(relu) << 32) | ~index   (atomicMax: largest value, then lowest index)
+//   min key = (bits(relu) << 32) |  index   (atomicMin: smallest value, then lowest index)   (relu >= 0: bits are ordered)
+__global__ __launch_bounds__(256) void plane_stats_partial_kernel(const float* __restrict__ U, unsigned long long* __restrict__ kmax,
+                                                                  unsigned long long* __restrict__ kmin, float* __restrict__ ksum,
+                                                                  int npix, int chunks) {
+  __shared__ unsigned long long s_mx[256], s_mn[256];
+  __shared__ float s_sum[256];
+  const int pl = blockIdx.x / chunks, ck = blockIdx.x - pl * chunks, tid = threadIdx.x;
   const float* p = U + (size_t)pl * npix;
-  float mx = -1.f, mn = INFINITY, sum = 0.f;
-  int imx = 0, imn = 0;
-  for (int i = tid; i < npix; i += 256) {
+  const int per = (npix + chunks - 1) / chunks;
+  const int i0 = ck * per, i1 = min(npix, i0 + per);
+  unsigned long long mx = 0ull, mn = ~0ull;
+  float sum = 0.f;
+  for (int i = i0 + tid; i < i1; i += 256) {
     const float u = p[i];
-    const float r = fmaxf(u, 0.f);
+    const unsigned rb = __float_as_uint(fmaxf(u, 0.f));
     sum += u;
-    if (r > mx) { mx = r; imx = i; }
-    if (r < mn) { mn = r; imn = i; }
+    const unsigned long long a = ((unsigned long long)rb << 32) | (unsigned)(~i), b = ((unsigned long long)rb << 32) | (unsigned)i;
+    mx = a > mx ? a : mx; mn = b < mn ? b : mn;
   }
-  s_mx[tid] = mx; s_mn[tid] = mn; s_sum[tid] = sum; s_imx[tid] = imx; s_imn[tid] = imn;
+  s_mx[tid] = mx; s_mn[tid] = mn; s_sum[tid] = sum;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
     if (tid < o) {
-      if (s_mx[tid + o] > s_mx[tid] || (s_mx[tid + o] == s_mx[tid] && s_imx[tid + o] < s_imx[tid])) { s_mx[tid] = s_mx[tid + o]; s_imx[tid] = s_imx[tid + o]; }
-      if (s_mn[tid + o] < s_mn[tid] || (s_mn[tid + o] == s_mn[tid] && s_imn[tid + o] < s_imn[tid])) { s_mn[tid] = s_mn[tid + o]; s_imn[tid] = s_imn[tid + o]; }
+      if (s_mx[tid + o] > s_mx[tid]) s_mx[tid] = s_mx[tid + o];
+      if (s_mn[tid + o] < s_mn[tid]) s_mn[tid] = s_mn[tid + o];
       s_sum[tid] += s_sum[tid + o];
     }
     __syncthreads();
   }
-  if (tid == 0) {
-    float* o = stats + (size_t)pl * 6;
-    o[0] = s_mx[0]; o[1] = s_mn[0]; o[2] = s_sum[0]; o[3] = __int_as_float(s_imx[0]); o[4] = __int_as_float(s_imn[0]); o[5] = 0.f;
-  }
+  if (tid == 0) { atomicMax(&kmax[pl], s_mx[0]); atomicMin(&kmin[pl], s_mn[0]); atomicAdd(&ksum[pl], s_sum[0]); }
+}
+__global__ void plane_stats_final_kernel(const unsigned long long* __restrict__ kmax, const unsigned long long* __restrict__ kmin,
+                                         const float* __restrict__ ksum, float* __restrict__ stats, long planes) {
+  const long pl = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pl >= planes) return;
+  float* o = stats + pl * 6;
+  o[0] = __uint_as_float((unsigned)(kmax[pl] >> 32)); o[1] = __uint_as_float((unsigned)(kmin[pl] >> 32)); o[2] = ksum[pl];
+  o[3] = __int_as_float((int)(~(unsigned)(kmax[pl] & 0xFFFFFFFFull))); o[4] = __int_as_float((int)(unsigned)(kmin[pl] & 0xFFFFFFFFull)); o[5] = 0.f;
 }
 
 // ---- classification loss (contrast_train.py:142,155,159-160): z = GAP, mean BCE-with-logits over N*20
@@ -725,9 +737,19 @@ __global__ __launch_bounds__(256) void nce_loss_grad_kernel(const float* __restr
 #define GRID1(total) dim3((unsigned)(((total) + 255) / 256)), dim3(256)
 #define ST ((hipStream_t)stream)
 
-extern "C" int wseg_plane_stats(const float* U, float* stats, long planes, int npix, void* stream) {
-  WSEG_CHECK(U && stats && planes > 0 && npix > 0, "plane_stats: bad arguments");
-  hipLaunchKernelGGL(plane_stats_kernel, dim3((unsigned)planes), dim3(256), 0, ST, U, stats, npix);
+// workspace: planes * 24 bytes (wseg_plane_stats_workspace_bytes)
+extern "C" size_t wseg_plane_stats_workspace_bytes(long planes) { return (size_t)planes * 24; }
+extern "C" int wseg_plane_stats(const float* U, float* stats, long planes, int npix, void* workspace, void* stream) {
+  WSEG_CHECK(U && stats && workspace && planes > 0 && npix > 0, "plane_stats: bad arguments");
+  unsigned long long* kmax = (unsigned long long*)workspace;
+  unsigned long long* kmin = kmax + planes;
+  float* ksum = (float*)(kmin + planes);
+  (void)hipMemsetAsync(kmax, 0x00, sizeof(unsigned long long) * planes, ST);
+  (void)hipMemsetAsync(kmin, 0xFF, sizeof(unsigned long long) * planes, ST);
+  (void)hipMemsetAsync(ksum, 0x00, sizeof(float) * planes, ST);
+  const int chunks = std::max(1, std::min(std::min(64, (int)((long)npix / 8192)), (int)std::max(1L, 2048 / planes)));
+  hipLaunchKernelGGL(plane_stats_partial_kernel, dim3((unsigned)(planes * chunks)), dim3(256), 0, ST, U, kmax, kmin, ksum, npix, chunks);
+  hipLaunchKernelGGL(plane_stats_final_kernel, dim3((unsigned)((planes + 255) / 256)), dim3(256), 0, ST, kmax, kmin, ksum, stats, planes);
   WSEG_LAUNCH_CHECK();
   return 0;
 }

@@ -9,6 +9,8 @@ of network/resnet38d.py:160-189 and network/resnet38_contrast.py:31-75.  Activat
 The whole network is one torch.autograd.Function: its backward runs the hand-written dgrad /
 wgrad / PCM-backward kernels and accumulates straight into the flat gradient buffer.
 """
+import os
+
 import torch
 
 from . import arch
@@ -141,16 +143,26 @@ class Engine:
             return self.packs
         P = {"w": dict(self._frozen_packs["w"]), "wt": {}, "bn": self._frozen_packs["bn"]}
         no_dgrad = {"b3.conv_branch1", "b3.conv_branch2a"}
+        # forward packs [OC][T][IC] have exactly the layout of the flat master buffer: in f32 mode they ARE views of
+        # it, in bf16 mode they are views of ONE cast copy (a single launch instead of one per layer)
+        if dt == L.BF16:
+            if getattr(self, "flat_wb", None) is None or self.flat_wb.numel() != self.flat_w.numel() or self.flat_wb.device != device:
+                self.flat_wb = torch.empty(self.flat_w.numel(), device=device, dtype=torch.bfloat16)
+            L.to_bf16(self.flat_w, self.flat_wb)
+            mirror = self.flat_wb
+        else:
+            mirror = self.flat_w
         for b in arch.BLOCKS:
             if b[0] in arch.FROZEN_BLOCKS:
                 continue
             for (cname, ci, co, k, s, d) in arch.block_convs(b):
-                w = self.conv_param(cname).detach()
                 T = k * k
-                wf = torch.empty(co, T, ci, device=device, dtype=tdt)
-                wt = torch.empty(ci, T, co, device=device, dtype=tdt) if cname not in no_dgrad else None
-                L.pack_weights(w, wf, wt, co, T, ci, co, ci, dt)
-                P["w"][cname], P["wt"][cname] = wf, wt
+                off, n = self.offsets[cname]
+                P["w"][cname] = mirror[off:off + n].view(co, T, ci)
+                if cname not in no_dgrad:
+                    wt = torch.empty(ci, T, co, device=device, dtype=tdt)
+                    L.pack_weights(self.flat_w[off:off + n], None, wt, co, T, ci, co, ci, dt)
+                    P["wt"][cname] = wt
         # fused head: rows [fc_proj | fc8 | 0]; its transposed pack is made from the two f32 masters directly
         wh = torch.zeros(HEAD_LD, 1, 4096, device=device, dtype=tdt)
         wht = torch.zeros(4096, 1, HEAD_LD, device=device, dtype=tdt)
@@ -160,9 +172,8 @@ class Engine:
         L.pack_weights(self.flat_w[off:off + 149 * 4096], None, wht, 149, 1, 4096, HEAD_LD, 4096, dt)
         P["w"]["head"], P["wt"]["head"] = wh, wht
         for nm, (co, ci) in (("f8_3", (64, 512)), ("f8_4", (128, 1024))):
-            wf = torch.empty(co, 1, ci, device=device, dtype=tdt)
-            L.pack_weights(getattr(net, nm).weight.detach(), wf, None, co, 1, ci, co, ci, dt)
-            P["w"][nm] = wf
+            off, n = self.offsets[nm]
+            P["w"][nm] = mirror[off:off + n].view(co, 1, ci)
         # f9: input columns re-ordered to the internal feature layout [f8_3 | f8_4 | x_s | pad]
         w9 = net.f9.weight.detach().reshape(192, 195)
         w9p = torch.cat([w9[:, 3:67], w9[:, 67:195], w9[:, 0:3]], dim=1).contiguous()
@@ -376,11 +387,30 @@ class Engine:
         def seg(din, dout):
             return (din[1][0], din[1][1], dout[1][0], dout[1][1]) if V == 2 else None
 
+        # Weight gradients only feed flat_g: with WSEG_WGRAD_STREAM=1 they run on a second HIP stream so that the
+        # partially filled last round of a dgrad launch (1 workgroup / CU kernels) is back-filled by wgrad
+        # workgroups and vice versa.  Operands are kept alive until the streams join.
+        main = torch.cuda.current_stream(dev)
+        wstream = None
+        if os.environ.get("WSEG_WGRAD_STREAM", "0") == "1":
+            wstream = getattr(self, "_wgrad_stream", None)
+            if wstream is None or wstream.device != dev:
+                wstream = self._wgrad_stream = torch.cuda.Stream(dev)
+            wstream.wait_stream(main)
+        keep = []
+
         def wgrad(nm, x, dy, cin, cout, k, stride, dil, din, dout, **kw):
             if trainable(nm):
                 off, n = self.offsets[nm]
-                L.conv_wgrad(x, dy, self.flat_g[off:off + n], N=N, IH=din[0][0], IW=din[0][1], IC=cin, OH=dout[0][0], OW=dout[0][1],
-                             OC=cout, KH=k, KW=k, stride=stride, dil=dil, pad=dil * (k // 2), seg2=seg(din, dout), **kw)
+                args = dict(N=N, IH=din[0][0], IW=din[0][1], IC=cin, OH=dout[0][0], OW=dout[0][1],
+                            OC=cout, KH=k, KW=k, stride=stride, dil=dil, pad=dil * (k // 2), seg2=seg(din, dout), **kw)
+                if wstream is None:
+                    L.conv_wgrad(x, dy, self.flat_g[off:off + n], **args)
+                else:
+                    keep.append((x, dy))
+                    wstream.wait_event(main.record_event())
+                    with torch.cuda.stream(wstream):
+                        L.conv_wgrad(x, dy, self.flat_g[off:off + n], **args)
 
         def dgrad(dy, wname, out, conv_cin, conv_cout, k, stride, dil, din, dout, **kw):
             # in = dY over the conv's OUTPUT dims (dout), out = dX over its INPUT dims (din)
@@ -503,6 +533,9 @@ class Engine:
                 Din = E(Mi, cin)
                 dgrad(du1, name + ".conv_branch2a", Din, cin, c4, 1, stride, 1, din, dout, epi=1, scale=sa, mask=sv["t"], r_pre=tmp)
                 D = Din
+        if wstream is not None:
+            main.wait_stream(wstream)
+            keep.clear()
 
 
 class _NetFunction(torch.autograd.Function):
