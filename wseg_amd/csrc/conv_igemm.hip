@@ -551,7 +551,7 @@ extern "C" int wseg_conv_igemm(const wseg_conv_desc* d, void* stream) {
   if (d->dtype == WSEG_BF16 && d->OC % 256 == 0 && d->bm_hint != 64 && d->bm_hint != 128 && d->bm_hint >= 0) {
     const long t256 = ((M + 255) / 256) * ((d->OC + 255) / 256);
     const long rounds = (t256 + 255) / 256;
-    static const int auto256 = getenv("WSEG_CONV256") ? atoi(getenv("WSEG_CONV256")) : 0;
+    static const int auto256 = getenv("WSEG_CONV256") ? atoi(getenv("WSEG_CONV256")) : 1;   // (0: A/B switch)
     big = d->bm_hint == 256 || (auto256 && t256 >= 200 && (double)t256 / (double)(rounds * 256) >= 0.80);
     if (big)
       WSEG_CHECK(d->IH <= 16384 && d->IW <= 16384 && d->OH <= 16384 && d->OW <= 16384 && d->pad <= 4096 &&

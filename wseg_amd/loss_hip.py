@@ -108,9 +108,10 @@ def _prototypes(v, label20, bg_threshold, tie_idx, N, world):
     if world > 1:                                        # global-batch prototypes: exchange candidates over RCCL
         gv, gf = _f32(world, 21, K, dev=dev), _f32(world, 21, K, 128, dev=dev)
         gc = torch.empty(world, 21, device=dev, dtype=torch.int32)
-        dist.all_gather_into_tensor(gv, cv)
-        dist.all_gather_into_tensor(gf, cf)
-        dist.all_gather_into_tensor(gc, cc)
+        # (outputs as dim-0 concatenations: the form both RCCL and gloo accept)
+        dist.all_gather_into_tensor(gv.view(world * 21, K), cv)
+        dist.all_gather_into_tensor(gf.view(world * 21, K, 128), cf)
+        dist.all_gather_into_tensor(gc.view(world * 21), cc)
         cv, cf, cc = gv, gf, gc
     v.protos = _f32(21, 128, dev=dev)
     L.proto_merge(cv, cf, cc, v.protos, world, K)
