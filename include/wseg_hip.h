@@ -166,6 +166,23 @@ int wseg_pcm_backward_bf16(const void* Fb, const void* Gb, const float* d_cam_rv
  */
 size_t wseg_plane_stats_workspace_bytes(long planes);
 int wseg_plane_stats(const float* U, float* stats, long planes, int npix, void* workspace, void* stream);
+/* The same map losses evaluated ON THE FLY from the stride-8 maps `low` [planes][h][w] (csrc/maps.hip): the
+ * reference's upsampled [N,21,S,S] tensors (resnet38_contrast.py:57-59, 540 MB per view) and their gradients are
+ * never materialised; U(y,x) = bilinear(low, align_corners=True) is recomputed by one pinned expression.
+ *  up_plane_stats          = plane_stats(U)                      (contrast_train.py:142,155; visualization.py:62-67)
+ *  up_rvmin_values         = rvmin_values(U_rv)                  (:16-22)
+ *  up_norm_resize_forward  = norm_resize_forward(U)              (:145-158)
+ *  resize_adjoint_ones     wvec[y] = sum over the S upsampled rows of their weight on low-res row y (the GAP gradient)
+ *  up_maps_backward        d_low[pl] = all gradients of plane pl: max_norm + resize backward of G (NULL: none) with the
+ *                          max/min routes, plane_bias[pl]*wvec_y*wvec_x (NULL: none), and the min-pool selection
+ *                          (q/argc/res of select_kth, NULL: none; k, coef as in rvmin_backward). */
+int wseg_up_plane_stats(const float* low, float* stats, long planes, int h, int w, int S, void* workspace, void* stream);
+int wseg_up_rvmin_values(const float* low, const float* label20, float* q, unsigned char* argc, int N, int h, int w, int S, void* stream);
+int wseg_up_norm_resize_forward(const float* low, const float* stats, const float* label20, float* out, int N, int h, int w, int S, int OS, void* stream);
+int wseg_resize_adjoint_ones(float* wvec, int h, int S, void* stream);
+int wseg_up_maps_backward(const float* G, const float* low, const float* stats, const float* label20, const float* plane_bias,
+                          const float* wvec_y, const float* wvec_x, const float* q, const unsigned char* argc, const float* res,
+                          int k, float coef, float* d_low, int N, int h, int w, int S, int OS, void* stream);
 int wseg_cls_loss(const float* stats, const float* label20, float* loss_out, float* plane_bias, int N, int npix, float coef, void* stream);
 int wseg_rvmin_values(const float* U, const float* label20, float* q, unsigned char* argc, int N, int npix, void* stream);
 size_t wseg_select_workspace_bytes(int rows);

@@ -110,3 +110,69 @@ def test_fused_sgd_matches_reference_fixture(golden_dir):
     for i in range(3):
         got = p[offs[i]:offs[i] + sizes[i]].cpu().numpy()
         np.testing.assert_allclose(got, g[f"p{i}_final"].reshape(-1), rtol=2e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("S,h", [(160, 20), (128, 16), (100, 13)])
+def test_maps_on_the_fly_match_materialised(S, h):
+    """csrc/maps.hip (no [N,21,S,S] tensors) against the materialising kernels of csrc/loss.hip on the same inputs:
+    plane statistics / min-pool values exact up to the resize rounding, forward maps and low-res gradients to 1e-5."""
+    from wseg_amd import _lib as L
+    dev = "cuda"
+    N, OS = 3, 128
+    g = torch.Generator().manual_seed(S)
+    low = (torch.rand(N, 21, h, h, generator=g) * 2 - 0.6).to(dev)        # mixed signs (cam); rv maps are >= 0
+    low_rv = torch.rand(N, 21, h, h, generator=g).to(dev)
+    lab = (torch.rand(N, 20, generator=g) < 0.25).float()
+    lab[:, 3] = 1
+    lab = lab.to(dev)
+    npix = S * S
+    f32 = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
+    for lo in (low, low_rv):
+        U = f32(N, 21, S, S)
+        L.resize_planar_fwd(lo, U, N * 21, h, h, S, S, True)
+        st_ref, st = f32(N * 21, 6), f32(N * 21, 6)
+        L.plane_stats(U, st_ref, N * 21, npix)
+        L.up_plane_stats(lo, st, N * 21, h, h, S)
+        assert torch.allclose(st[:, :2], st_ref[:, :2], rtol=1e-6, atol=1e-7)
+        assert torch.allclose(st[:, 2], st_ref[:, 2], rtol=1e-4, atol=1e-2)
+        Uf = U.reshape(N * 21, npix).clamp(min=0)
+        imx, imn = st[:, 3].view(torch.int32).long(), st[:, 4].view(torch.int32).long()
+        assert torch.allclose(Uf.gather(1, imx[:, None])[:, 0], st[:, 0], rtol=1e-6, atol=1e-7)
+        assert torch.allclose(Uf.gather(1, imn[:, None])[:, 0], st[:, 1], rtol=1e-6, atol=1e-7)
+        out_ref, out = f32(N, 21, OS, OS), f32(N, 21, OS, OS)
+        L.norm_resize_forward(U, st_ref, lab, out_ref, N, S, OS)
+        L.up_norm_resize_forward(lo, st, lab, out, N, h, h, S, OS)
+        assert torch.allclose(out, out_ref, rtol=1e-5, atol=1e-5)
+    # min-pool values + the complete backward of the rv map
+    U = f32(N, 21, S, S)
+    L.resize_planar_fwd(low_rv, U, N * 21, h, h, S, S, True)
+    q_ref, q = f32(N, npix), f32(N, npix)
+    a_ref, a = torch.empty(N, npix, device=dev, dtype=torch.uint8), torch.empty(N, npix, device=dev, dtype=torch.uint8)
+    L.rvmin_values(U, lab, q_ref, a_ref, N, npix)
+    L.up_rvmin_values(low_rv, lab, q, a, N, h, h, S)
+    assert torch.allclose(q, q_ref, rtol=1e-6, atol=1e-7)
+    assert float((a != a_ref).float().mean()) < 1e-3                      # arg channel may flip only on rounding ties
+    k = npix // 4
+    res = f32(N, 4)
+    ws = torch.empty(L.select_workspace_bytes(N), device=dev, dtype=torch.uint8)
+    L.select_kth(q, N, npix, k, False, False, True, res, ws)
+    G = (torch.rand(N, 21, OS, OS, generator=g) - 0.5).to(dev)
+    bias = (torch.rand(N * 21, generator=g) - 0.5).to(dev) * 1e-3
+    coef = 0.5 / (k * N)
+    for lo, use_q, use_bias in ((low_rv, True, False), (low, False, True)):
+        U = f32(N, 21, S, S)
+        L.resize_planar_fwd(lo, U, N * 21, h, h, S, S, True)
+        st = f32(N * 21, 6)
+        L.up_plane_stats(lo, st, N * 21, h, h, S)
+        dU = torch.zeros(N, 21, S, S, device=dev)
+        L.norm_resize_backward(G, U, st, lab, dU, N, S, OS)
+        if use_q:
+            L.rvmin_backward(q, a, res, lab, dU, N, npix, k, coef)
+        d_ref, d = f32(N, 21, h, h), f32(N, 21, h, h)
+        L.resize_planar_bwd(dU, d_ref, N * 21, h, h, S, S, True, plane_add=bias if use_bias else None)
+        wv = f32(h)
+        L.resize_adjoint_ones(wv, h, S)
+        L.up_maps_backward(G, lo, st, lab, bias if use_bias else None, wv if use_bias else None, wv if use_bias else None,
+                           q if use_q else None, a if use_q else None, res if use_q else None, k, coef, d, N, h, h, S, OS)
+        scale = float(d_ref.abs().max())
+        assert float((d - d_ref).abs().max()) <= 2e-5 * scale, (float((d - d_ref).abs().max()), scale)

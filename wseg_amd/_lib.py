@@ -237,6 +237,18 @@ def nce_loss_grad(fn, nrm, S_own, S_oth, y_own, y_oth, w_intra, p_own, p_oth, dF
     _call("wseg_nce_loss_grad", _v(fn), _v(nrm), _v(S_own), _v(S_oth), _v(y_own), _v(y_oth), _v(w_intra), _v(p_own), _v(p_oth), _v(dF), _v(sums), P, _f(coef_cross), _f(coef_intra))
 
 
+# ---- SEAM map losses evaluated on the fly from the stride-8 maps (csrc/maps.hip): no [N,21,S,S] tensors
+def up_plane_stats(low, stats, planes, h, w, S):
+    ws = torch.empty(int(lib.wseg_plane_stats_workspace_bytes(C.c_long(planes))), device=low.device, dtype=torch.uint8)
+    _call("wseg_up_plane_stats", _v(low), _v(stats), C.c_long(planes), h, w, S, _v(ws))
+def up_rvmin_values(low, label20, q, argc, N, h, w, S): _call("wseg_up_rvmin_values", _v(low), _v(label20), _v(q), _v(argc), N, h, w, S)
+def up_norm_resize_forward(low, stats, label20, out, N, h, w, S, OS): _call("wseg_up_norm_resize_forward", _v(low), _v(stats), _v(label20), _v(out), N, h, w, S, OS)
+def resize_adjoint_ones(wvec, h, S): _call("wseg_resize_adjoint_ones", _v(wvec), h, S)
+def up_maps_backward(G, low, stats, label20, plane_bias, wvec_y, wvec_x, q, argc, res, k, coef, d_low, N, h, w, S, OS):
+    _call("wseg_up_maps_backward", _v(G), _v(low), _v(stats), _v(label20), _v(plane_bias), _v(wvec_y), _v(wvec_x), _v(q), _v(argc), _v(res),
+          k, _f(coef), _v(d_low), N, h, w, S, OS)
+
+
 def gemm256_probe(A, B, Cout, M, N, K, variant=0):
     check(lib.wseg_gemm256_probe(_v(A), _v(B), _v(Cout), M, N, K, variant, _s()), "wseg_gemm256_probe")
 

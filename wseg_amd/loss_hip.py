@@ -45,24 +45,34 @@ class _View:
     pass
 
 
+_WVEC = {}
+
+
+def _adjoint_ones(h, S, dev):
+    """wvec[y] = total weight of low-res row y in the align_corners upsample h -> S (the GAP gradient pattern)."""
+    key = (h, S, str(dev))
+    if key not in _WVEC:
+        wv = torch.empty(h, device=dev, dtype=torch.float32)
+        L.resize_adjoint_ones(wv, h, S)
+        _WVEC[key] = wv
+    return _WVEC[key]
+
+
 def _maps_forward(v, label20, acc, N):
-    """Upsample, plane statistics, cls + rvmin losses, max-norm + 128x128 resize for one view."""
+    """Plane statistics, cls + rvmin losses, max-norm + 128x128 resize for one view — all evaluated on the fly from
+    the stride-8 maps (csrc/maps.hip): the [N,21,S,S] upsampled maps of the reference are never materialised."""
     dev = v.cam_low.device
     S, h, w = v.S, v.h, v.w
     npix = S * S
-    v.U_cam = _f32(N, 21, S, S, dev=dev)
-    v.U_rv = _f32(N, 21, S, S, dev=dev)
-    L.resize_planar_fwd(v.cam_low, v.U_cam, N * 21, h, w, S, S, True)
-    L.resize_planar_fwd(v.rvd, v.U_rv, N * 21, h, w, S, S, True)
     v.st_cam = _f32(N * 21, 6, dev=dev)
     v.st_rv = _f32(N * 21, 6, dev=dev)
-    L.plane_stats(v.U_cam, v.st_cam, N * 21, npix)
-    L.plane_stats(v.U_rv, v.st_rv, N * 21, npix)
+    L.up_plane_stats(v.cam_low, v.st_cam, N * 21, h, w, S)
+    L.up_plane_stats(v.rvd, v.st_rv, N * 21, h, w, S)
     v.bias = _f32(N * 21, dev=dev)
     L.cls_loss(v.st_cam, label20, acc[0:1], v.bias, N, npix, 0.5)
     v.q = _f32(N, npix, dev=dev)
     v.argc = torch.empty(N, npix, device=dev, dtype=torch.uint8)
-    L.rvmin_values(v.U_rv, label20, v.q, v.argc, N, npix)
+    L.up_rvmin_values(v.rvd, label20, v.q, v.argc, N, h, w, S)
     v.k_min = npix // 4
     v.res_min = _f32(N, 4, dev=dev)
     ws = torch.empty(L.select_workspace_bytes(N), device=dev, dtype=torch.uint8)
@@ -70,22 +80,19 @@ def _maps_forward(v, label20, acc, N):
     L.select_finish(v.res_min, N, v.k_min, True, 0.5 / (v.k_min * N), acc[1:2])
     v.c = _f32(N, 21, 128, 128, dev=dev)
     v.r = _f32(N, 21, 128, 128, dev=dev)
-    L.norm_resize_forward(v.U_cam, v.st_cam, label20, v.c, N, S, 128)
-    L.norm_resize_forward(v.U_rv, v.st_rv, label20, v.r, N, S, 128)
+    L.up_norm_resize_forward(v.cam_low, v.st_cam, label20, v.c, N, h, w, S, 128)
+    L.up_norm_resize_forward(v.rvd, v.st_rv, label20, v.r, N, h, w, S, 128)
 
 
 def _maps_backward(v, label20, N):
     dev = v.cam_low.device
     S, h, w = v.S, v.h, v.w
-    dU = torch.zeros(N, 21, S, S, device=dev, dtype=torch.float32)
-    L.norm_resize_backward(v.Gc, v.U_cam, v.st_cam, label20, dU, N, S, 128)
+    wy, wx = _adjoint_ones(h, S, dev), _adjoint_ones(w, S, dev)
     v.d_cam_low = _f32(N, 21, h, w, dev=dev)
-    L.resize_planar_bwd(dU, v.d_cam_low, N * 21, h, w, S, S, True, plane_add=v.bias)
-    dU.zero_()
-    L.norm_resize_backward(v.Gr, v.U_rv, v.st_rv, label20, dU, N, S, 128)
-    L.rvmin_backward(v.q, v.argc, v.res_min, label20, dU, N, S * S, v.k_min, 0.5 / (v.k_min * N))
+    L.up_maps_backward(v.Gc, v.cam_low, v.st_cam, label20, v.bias, wy, wx, None, None, None, 0, 0.0, v.d_cam_low, N, h, w, S, 128)
     v.d_rvd = _f32(N, 21, h, w, dev=dev)
-    L.resize_planar_bwd(dU, v.d_rvd, N * 21, h, w, S, S, True)
+    L.up_maps_backward(v.Gr, v.rvd, v.st_rv, label20, None, None, None, v.q, v.argc, v.res_min, v.k_min, 0.5 / (v.k_min * N),
+                       v.d_rvd, N, h, w, S, 128)
 
 
 def _prototypes(v, label20, bg_threshold, tie_idx, N, world):
