@@ -92,6 +92,13 @@ int wseg_conv_wgrad(const wseg_wgrad_desc* d, void* stream);
  * (zero padded).  Either destination may be NULL. */
 int wseg_pack_weights(const float* master, void* fwd, void* tr, int OC, int T, int IC,
                       int OCp, int ICp, int dtype, void* stream);
+/* every transposed pack of a training step in ONE launch: layer l is the f32 master [OC][T][IC] at master + off_in[l],
+ * written as [IC][T][OC] in `dtype` at out + off_out[l] (element offsets).  `table` (device, int64) holds per layer
+ * {index of its first 32x32 tile, off_in, off_out, OC, T, IC}; total_tiles = sum of ceil(OC/32)*ceil(IC/32)*T. */
+int wseg_pack_transposed_batch(const float* master, void* out, const long* table, int nlayers, long total_tiles, int dtype, void* stream);
+/* Dropout2d scales (resnet38d.py:64,68,86,91; resnet38_contrast.py:14,34) from uniforms u in [0,1):
+ * out[i] = u[i] >= p ? 1/(1-p) : 0 with p = p0 for i < split_at, p1 after (one launch for all five masks). */
+int wseg_dropout_scale(const float* u, float* out, long total, long split_at, float p0, float p1, void* stream);
 
 /* ---- stem: conv1a (3->64, 3x3, pad 1) + the next block's frozen BN-ReLU -------------------
  * network/resnet38d.py:124,162 (+ :29-30 of b2).  x is the reference's NCHW f32 input;
@@ -201,6 +208,12 @@ int wseg_proto_candidates(const float* ncam, const float* F, const int* tie_idx,
 int wseg_proto_merge(const float* cand_val, const float* cand_feat, const int* cand_const, float* protos, int world, int K, void* stream);
 int wseg_nce_sims(const float* F, const float* p_own, const float* p_oth, float* fn, float* nrm, float* S_own, float* S_oth, int P, void* stream);
 int wseg_intra_weights(const int* y, const float* S_own, const float* rkey, const unsigned char* rand_flag, float* w, int P, void* stream);
+/* the same sampling over the GLOBAL batch under data parallelism (the reference runs :302-334 on the gathered batch):
+ * intra_pack writes this rank's records rec[3][P] = {label (int bits), own-class similarity, random key}; after an
+ * all-gather rank r's block lies at rec + r*rank_stride and intra_weights_global returns this rank's weights, multiplied by `scale`
+ * (= ranks when the gradient all-reduce averages). */
+int wseg_intra_pack(const int* y, const float* S_own, const float* rkey, float* rec, int P, void* stream);
+int wseg_intra_weights_global(const float* rec, float* w, int P, int ranks, int own_rank, float scale, long rank_stride, void* stream);
 int wseg_nce_loss_grad(const float* fn, const float* nrm, const float* S_own, const float* S_oth, const int* y_own, const int* y_oth,
                        const float* w_intra, const float* p_own, const float* p_oth, float* dF, float* sums, int P,
                        float coef_cross, float coef_intra, void* stream);

@@ -133,12 +133,12 @@ def test_maps_on_the_fly_match_materialised(S, h):
         st_ref, st = f32(N * 21, 6), f32(N * 21, 6)
         L.plane_stats(U, st_ref, N * 21, npix)
         L.up_plane_stats(lo, st, N * 21, h, h, S)
-        assert torch.allclose(st[:, :2], st_ref[:, :2], rtol=1e-6, atol=1e-7)
+        assert torch.allclose(st[:, :2], st_ref[:, :2], rtol=5e-6, atol=1e-6)
         assert torch.allclose(st[:, 2], st_ref[:, 2], rtol=1e-4, atol=1e-2)
         Uf = U.reshape(N * 21, npix).clamp(min=0)
         imx, imn = st[:, 3].view(torch.int32).long(), st[:, 4].view(torch.int32).long()
-        assert torch.allclose(Uf.gather(1, imx[:, None])[:, 0], st[:, 0], rtol=1e-6, atol=1e-7)
-        assert torch.allclose(Uf.gather(1, imn[:, None])[:, 0], st[:, 1], rtol=1e-6, atol=1e-7)
+        assert torch.allclose(Uf.gather(1, imx[:, None])[:, 0], st[:, 0], rtol=5e-6, atol=1e-6)
+        assert torch.allclose(Uf.gather(1, imn[:, None])[:, 0], st[:, 1], rtol=5e-6, atol=1e-6)
         out_ref, out = f32(N, 21, OS, OS), f32(N, 21, OS, OS)
         L.norm_resize_forward(U, st_ref, lab, out_ref, N, S, OS)
         L.up_norm_resize_forward(lo, st, lab, out, N, h, h, S, OS)
@@ -150,7 +150,7 @@ def test_maps_on_the_fly_match_materialised(S, h):
     a_ref, a = torch.empty(N, npix, device=dev, dtype=torch.uint8), torch.empty(N, npix, device=dev, dtype=torch.uint8)
     L.rvmin_values(U, lab, q_ref, a_ref, N, npix)
     L.up_rvmin_values(low_rv, lab, q, a, N, h, h, S)
-    assert torch.allclose(q, q_ref, rtol=1e-6, atol=1e-7)
+    assert torch.allclose(q, q_ref, rtol=5e-6, atol=1e-6)
     assert float((a != a_ref).float().mean()) < 1e-3                      # arg channel may flip only on rounding ties
     k = npix // 4
     res = f32(N, 4)
@@ -176,3 +176,35 @@ def test_maps_on_the_fly_match_materialised(S, h):
                            q if use_q else None, a if use_q else None, res if use_q else None, k, coef, d, N, h, h, S, OS)
         scale = float(d_ref.abs().max())
         assert float((d - d_ref).abs().max()) <= 2e-5 * scale, (float((d - d_ref).abs().max()), scale)
+
+
+@pytest.mark.parametrize("ranks", [1, 2])
+def test_intra_weights_global_matches_sorted_kernel(ranks):
+    """Hard-pixel sampling over the gathered batch (radix-select thresholds on the all-gathered records) against the
+    single-rank sort-based kernel run on the concatenated global arrays: identical weights for every rank's slice."""
+    from wseg_amd import _lib as L
+    dev = "cuda"
+    P = 1536
+    g = torch.Generator().manual_seed(11 + ranks)
+    PG = P * ranks
+    y = torch.randint(0, 21, (PG,), generator=g, dtype=torch.int32)
+    y[y == 7] = 3                                   # an absent class
+    y[5] = 19; y[y == 19] = 2; y[5] = 19            # a class with a single pixel (skipped, still counted)
+    S = (torch.rand(PG, 21, generator=g) * 2 - 1)
+    S[10:40, :] = S[9, :]                           # tied similarities: order falls back to the pixel index
+    y[10:40] = y[9]
+    rk = torch.rand(PG, generator=g)
+    rk[100:120] = rk[99]
+    y, S, rk = y.to(dev), S.to(dev), rk.to(dev)
+    w_ref = torch.empty(PG, device=dev)
+    L.intra_weights(y, S, rk, None, w_ref, PG)
+    rec = torch.empty(ranks, 3, P, device=dev)
+    for r in range(ranks):
+        sl = slice(r * P, (r + 1) * P)
+        L.intra_pack(y[sl].contiguous(), S[sl].contiguous(), rk[sl].contiguous(), rec[r], P)
+    for r in range(ranks):
+        w = torch.empty(P, device=dev)
+        L.intra_weights_global(rec, w, P, ranks, r, float(ranks), 3 * P)
+        ref = w_ref[r * P:(r + 1) * P] * ranks
+        assert float(ref.sum()) > 0
+        assert torch.allclose(w, ref, rtol=1e-6, atol=0), float((w - ref).abs().max())

@@ -141,3 +141,29 @@ def test_cam_miou_eval(tmp_path, lib):
     b = weval.do_eval(names, str(npy_dir), str(gt_dir), 'npy', 0.4)
     assert abs(a['mIoU'] - ref_miou) < 1e-9 and abs(b['mIoU'] - ref_miou) < 1e-9
     assert a['bird'] > 0 and a['person'] > 0 and a['aeroplane'] == 0
+
+
+def test_gradient_buckets_tile_the_flat_buffer():
+    """The overlap buckets of the gradient all-reduce (train.py) are contiguous, cover flat_g exactly once, and each
+    holds only parameters whose gradients are complete when its trigger block has been processed."""
+    import contextlib
+    import io
+    import torch
+    from wseg_amd import arch
+    from wseg_amd.resnet38_contrast import Net
+    net = Net()
+    with contextlib.redirect_stdout(io.StringIO()):
+        net.get_parameter_groups()
+    eng = net._engine
+    eng.ensure_flat(torch.device("cpu"))
+    buckets = eng.grad_buckets()
+    order = [b[0] for b in arch.BLOCKS if b[0] not in arch.FROZEN_BLOCKS]          # forward order; backward runs it reversed
+    spans = sorted(buckets.values())
+    assert spans[0][0] == 0 and spans[-1][1] == eng.flat_g.numel()
+    assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    for trigger, (lo, hi) in buckets.items():
+        done = set(order[order.index(trigger):])                                   # blocks processed when `trigger` completes
+        for name, (off, n) in eng.offsets.items():
+            if lo <= off < hi:
+                blk = name.split(".")[0]
+                assert blk in done or blk in ("fc_proj", "fc8", "f8_3", "f8_4", "f9"), (trigger, name)

@@ -130,6 +130,16 @@ def pack_weights(master, fwd, tr, OC, T, IC, OCp, ICp, dtype):
                                 OC, T, IC, OCp, ICp, dtype, C.c_void_p(stream_ptr())), "wseg_pack_weights")
 
 
+def pack_transposed_batch(master, out, table, nlayers, total_tiles, dtype):
+    check(lib.wseg_pack_transposed_batch(C.c_void_p(_ptr(master)), C.c_void_p(_ptr(out)), C.c_void_p(_ptr(table)), nlayers,
+                                         C.c_long(total_tiles), dtype, C.c_void_p(stream_ptr())), "wseg_pack_transposed_batch")
+
+
+def dropout_scale(u, out, split_at, p0, p1):
+    check(lib.wseg_dropout_scale(C.c_void_p(_ptr(u)), C.c_void_p(_ptr(out)), C.c_long(u.numel()), C.c_long(split_at),
+                                 C.c_float(p0), C.c_float(p1), C.c_void_p(stream_ptr())), "wseg_dropout_scale")
+
+
 def stem_conv(x, w, scale, shift, raw, act, N, H, W, dtype):
     check(lib.wseg_stem_conv(C.c_void_p(_ptr(x)), C.c_void_p(_ptr(w)), C.c_void_p(_ptr(scale)), C.c_void_p(_ptr(shift)),
                              C.c_void_p(_ptr(raw)), C.c_void_p(_ptr(act)), N, H, W, dtype,
@@ -233,6 +243,8 @@ def proto_candidates(ncam, F, tie_idx, cand_val, cand_feat, cand_const, N, npix,
 def proto_merge(cand_val, cand_feat, cand_const, protos, world, K): _call("wseg_proto_merge", _v(cand_val), _v(cand_feat), _v(cand_const), _v(protos), world, K)
 def nce_sims(F, p_own, p_oth, fn, nrm, S_own, S_oth, P): _call("wseg_nce_sims", _v(F), _v(p_own), _v(p_oth), _v(fn), _v(nrm), _v(S_own), _v(S_oth), P)
 def intra_weights(y, S_own, rkey, rand_flag, w, P): _call("wseg_intra_weights", _v(y), _v(S_own), _v(rkey), _v(rand_flag), _v(w), P)
+def intra_pack(y, S_own, rkey, rec, P): _call("wseg_intra_pack", _v(y), _v(S_own), _v(rkey), _v(rec), P)
+def intra_weights_global(rec, w, P, ranks, own_rank, scale, rank_stride): _call("wseg_intra_weights_global", _v(rec), _v(w), P, ranks, own_rank, _f(scale), C.c_long(rank_stride))
 def nce_loss_grad(fn, nrm, S_own, S_oth, y_own, y_oth, w_intra, p_own, p_oth, dF, sums, P, coef_cross, coef_intra):
     _call("wseg_nce_loss_grad", _v(fn), _v(nrm), _v(S_own), _v(S_oth), _v(y_own), _v(y_oth), _v(w_intra), _v(p_own), _v(p_oth), _v(dF), _v(sums), P, _f(coef_cross), _f(coef_intra))
 

@@ -44,6 +44,41 @@ __global__ void pack_tr_kernel(const float* __restrict__ w, void* __restrict__ o
   }
 }
 
+// ---- all transposed packs of one step in ONE launch: layer l = master f32 [OC][T][IC] at master + off_in[l]
+//      -> [IC][T][OC] (dtype) at out + off_out[l] (elements).  table[l] = {first 32x32 tile, off_in, off_out, OC, T, IC}.
+template <int DT>
+__global__ void pack_tr_batch_kernel(const float* __restrict__ master, void* __restrict__ out, const long* __restrict__ table, int nlayers) {
+  __shared__ float tile[32][33];
+  const long bid = blockIdx.x;
+  int lo = 0, hi = nlayers - 1;                    // last layer whose first tile <= bid
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (table[mid * 6] <= bid) lo = mid; else hi = mid - 1; }
+  const long* e = table + lo * 6;
+  const int OC = (int)e[3], T = (int)e[4], IC = (int)e[5];
+  const int nti = (IC + 31) / 32, nto = (OC + 31) / 32;
+  long r = bid - e[0];
+  const int ti = (int)(r % nti); r /= nti;
+  const int to = (int)(r % nto); const int t = (int)(r / nto);
+  const float* w = master + e[1];
+  const int oc0 = to * 32, ic0 = ti * 32;
+  for (int rr = threadIdx.y; rr < 32; rr += 8) {
+    const int oc = oc0 + rr, ic = ic0 + threadIdx.x;
+    tile[rr][threadIdx.x] = (oc < OC && ic < IC) ? w[((size_t)oc * T + t) * IC + ic] : 0.f;
+  }
+  __syncthreads();
+  for (int rr = threadIdx.y; rr < 32; rr += 8) {
+    const int ic = ic0 + rr, oc = oc0 + threadIdx.x;
+    if (ic < IC && oc < OC) elem<DT>::st(out, (size_t)e[2] + ((size_t)ic * T + t) * OC + oc, tile[threadIdx.x][rr]);
+  }
+}
+
+// ---- Dropout2d scales for one step from uniforms: out[i] = u[i] >= p ? 1/(1-p) : 0, p = p0 for i < split_at else p1
+__global__ void dropout_scale_kernel(const float* __restrict__ u, float* __restrict__ out, long total, long split_at, float p0, float p1) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const float p = i < split_at ? p0 : p1;
+  out[i] = u[i] >= p ? 1.f / (1.f - p) : 0.f;
+}
+
 // ---- stem: conv1a 3->64 3x3 pad 1 from NCHW f32, fused BN-ReLU, NHWC out -------------------
 template <int DT>
 __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, const float* __restrict__ w,
@@ -142,6 +177,22 @@ extern "C" int wseg_stem_conv(const float* x, const float* w, const float* scale
   hipStream_t s = (hipStream_t)stream;
   if (dtype == WSEG_BF16) hipLaunchKernelGGL(stem_kernel<WSEG_BF16>, dim3((unsigned)blocks), dim3(256), 0, s, x, w, scale, shift, raw, act, N, H, W);
   else hipLaunchKernelGGL(stem_kernel<WSEG_F32>, dim3((unsigned)blocks), dim3(256), 0, s, x, w, scale, shift, raw, act, N, H, W);
+  WSEG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wseg_pack_transposed_batch(const float* master, void* out, const long* table, int nlayers, long total_tiles, int dtype, void* stream) {
+  WSEG_CHECK(master && out && table && nlayers > 0 && total_tiles > 0 && total_tiles < (1L << 31), "pack_transposed_batch: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == WSEG_BF16) hipLaunchKernelGGL(pack_tr_batch_kernel<WSEG_BF16>, dim3((unsigned)total_tiles), dim3(32, 8), 0, s, master, out, table, nlayers);
+  else hipLaunchKernelGGL(pack_tr_batch_kernel<WSEG_F32>, dim3((unsigned)total_tiles), dim3(32, 8), 0, s, master, out, table, nlayers);
+  WSEG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wseg_dropout_scale(const float* u, float* out, long total, long split_at, float p0, float p1, void* stream) {
+  WSEG_CHECK(u && out && total > 0 && p0 >= 0.f && p0 < 1.f && p1 >= 0.f && p1 < 1.f, "dropout_scale: bad arguments");
+  hipLaunchKernelGGL(dropout_scale_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, u, out, total, split_at, p0, p1);
   WSEG_LAUNCH_CHECK();
   return 0;
 }

@@ -134,22 +134,39 @@ __global__ __launch_bounds__(256) void select_hist_kernel(const float* __restric
   __syncthreads();
   if (h[threadIdx.x]) atomicAdd(&hist[row * 256 + threadIdx.x], h[threadIdx.x]);
 }
-// choose the bucket holding the k-th (k counted from the small end: 1-based rank) and narrow the prefix
-__global__ void select_scan_kernel(unsigned* __restrict__ state, unsigned* __restrict__ hist, int shift, int rows) {
-  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+// choose the bucket holding the k-th (k counted from the small end: 1-based rank) and narrow the prefix.
+// One wave per row: lane l owns buckets 4l..4l+3, a shuffle scan finds the lane whose running count crosses k.
+__global__ __launch_bounds__(64) void select_scan_kernel(unsigned* __restrict__ state, unsigned* __restrict__ hist, int shift, int rows) {
+  const int row = blockIdx.x, lane = threadIdx.x;
   if (row >= rows) return;
-  unsigned k = state[row * 4 + 2];
-  unsigned cum = 0; int b = 0;
-  for (b = 0; b < 256; ++b) {
-    const unsigned c = hist[row * 256 + b];
-    if (cum + c >= k) break;
-    cum += c;
+  const unsigned k = state[row * 4 + 2];
+  uint4* hrow = reinterpret_cast<uint4*>(hist + (size_t)row * 256);
+  const uint4 c = hrow[lane];
+  const unsigned s = c.x + c.y + c.z + c.w;
+  unsigned inc = s;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
   }
-  if (b > 255) b = 255;
-  state[row * 4 + 0] |= ((unsigned)b << shift);
-  state[row * 4 + 1] |= (255u << shift);
-  state[row * 4 + 2] = k - cum;
-  for (int i = 0; i < 256; ++i) hist[row * 256 + i] = 0;
+  const unsigned exc = inc - s;
+  const unsigned total = __shfl(inc, 63, 64);
+  hrow[lane] = make_uint4(0u, 0u, 0u, 0u);
+  int b = -1; unsigned cum = exc;
+  if (exc < k && inc >= k) {                       // exactly one lane (k >= 1); first bucket with running count >= k
+    const unsigned cs[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (b < 0) { if (cum + cs[j] >= k) b = lane * 4 + j; else cum += cs[j]; }
+    }
+  } else if (lane == 63 && total < k) {            // (cannot happen for finite inputs: keep the serial loop's result)
+    b = 255; cum = total;
+  }
+  if (b >= 0) {
+    state[row * 4 + 0] |= ((unsigned)b << shift);
+    state[row * 4 + 1] |= (255u << shift);
+    state[row * 4 + 2] = k - cum;
+  }
 }
 __global__ void select_init_kernel(unsigned* __restrict__ state, unsigned* __restrict__ hist, int rows, unsigned rank_small) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -618,6 +635,92 @@ __global__ __launch_bounds__(1024) void intra_weights_kernel(const int* __restri
   }
 }
 
+// ---- hard-pixel sampling over the GLOBAL batch (data parallel; contrast_train.py:302-334 runs on the gathered batch).
+// intra_pack: this rank's per-pixel record {label, own-class similarity, random key} for the all-gather.
+__global__ void intra_pack_kernel(const int* __restrict__ y, const float* __restrict__ S_own, const float* __restrict__ rkey,
+                                  float* __restrict__ rec, int P) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const int c = y[p];
+  rec[p] = __int_as_float(c);
+  rec[P + p] = S_own[(size_t)p * 21 + c];
+  rec[2 * P + p] = rkey[p];
+}
+// intra_weights_global: `rec` = gathered records, rank r's [3][P] block at rec + r*rank_stride (global pixel g = r*P + p).  Per class c with
+// len >= 2 pixels the reference keeps (a) a random half and (b) the pixels whose similarity rank lies in
+// [int(0.6 len) - len/2, int(0.6 len)); both are order statistics of unique 56-bit keys (value << 24 | g), found
+// by a 7-pass radix select for all 21 x 3 thresholds at once (one workgroup, histograms in LDS) — no global sort.
+// Writes this rank's weights: w[p] = scale * (#selections of p) / (2 * (len/2) * classes present).
+__global__ __launch_bounds__(1024) void intra_weights_global_kernel(const float* __restrict__ rec, float* __restrict__ w, int P, int ranks,
+                                                                    int own_rank, float scale, long rank_stride) {
+  __shared__ unsigned hist[63][256];
+  __shared__ unsigned long long prefix[63];
+  __shared__ unsigned remaining[63];
+  __shared__ int cnt[21], nclass;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int PG = P * ranks;
+  auto label = [&](int g) { const int r = g / P; return __float_as_int(rec[(size_t)r * rank_stride + (g - r * P)]); };
+  auto key = [&](int g, int which) {              // which: 1 = similarity, 2 = random key
+    const int r = g / P;
+    return ((unsigned long long)f2key(rec[(size_t)r * rank_stride + (size_t)which * P + (g - r * P)]) << 24) | (unsigned long long)g;
+  };
+  if (tid < 21) cnt[tid] = 0;
+  __syncthreads();
+  for (int g = tid; g < PG; g += 1024) atomicAdd(&cnt[label(g)], 1);
+  __syncthreads();
+  if (tid == 0) { int C = 0; for (int c = 0; c < 21; ++c) if (cnt[c] > 0) ++C; nclass = C; }
+  if (tid < 63) {
+    const int c = tid / 3, j = tid - c * 3, len = cnt[c], half = len / 2, kk = (int)((double)len * 0.6);
+    prefix[tid] = 0ull;
+    remaining[tid] = (unsigned)(j == 0 ? kk - half : (j == 1 ? kk : half));     // 0-based target rank within the class
+  }
+  for (int shift = 48; shift >= 0; shift -= 8) {
+    for (int i = tid; i < 63 * 256; i += 1024) (&hist[0][0])[i] = 0u;
+    __syncthreads();
+    for (int g = tid; g < PG; g += 1024) {
+      const int c = label(g);
+      if (cnt[c] < 2) continue;
+      const unsigned long long ks = key(g, 1), kr = key(g, 2);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const unsigned long long k = j == 2 ? kr : ks;
+        const int s = c * 3 + j;
+        if (shift == 48 || (k >> (shift + 8)) == (prefix[s] >> (shift + 8))) atomicAdd(&hist[s][(unsigned)(k >> shift) & 255u], 1u);
+      }
+    }
+    __syncthreads();
+    for (int s = wv; s < 63; s += 16) {            // one wave per selection: lane l owns buckets 4l..4l+3
+      const unsigned rem = remaining[s];
+      const unsigned c0 = hist[s][lane * 4], c1 = hist[s][lane * 4 + 1], c2 = hist[s][lane * 4 + 2], c3 = hist[s][lane * 4 + 3];
+      const unsigned sum = c0 + c1 + c2 + c3;
+      unsigned inc = sum;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+      unsigned cum = inc - sum;
+      if (cum <= rem && rem < inc) {               // exactly one lane when the class holds more than `rem` pixels
+        const unsigned cs[4] = {c0, c1, c2, c3};
+        int b = -1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (b < 0) { if (rem < cum + cs[j]) b = lane * 4 + j; else cum += cs[j]; }
+        prefix[s] |= (unsigned long long)b << shift;
+        remaining[s] = rem - cum;
+      }
+    }
+    __syncthreads();
+  }
+  const int g0 = own_rank * P;
+  for (int p = tid; p < P; p += 1024) {
+    const int g = g0 + p, c = label(g), len = cnt[c];
+    float wp = 0.f;
+    if (len >= 2) {
+      const unsigned long long ks = key(g, 1), kr = key(g, 2);
+      const int n_sel = (ks >= prefix[c * 3 + 0] && ks < prefix[c * 3 + 1] ? 1 : 0) + (kr < prefix[c * 3 + 2] ? 1 : 0);
+      wp = scale * (float)n_sel / (2.f * (float)(len / 2) * (float)nclass);
+    }
+    w[p] = wp;
+  }
+}
+
 // ---- per-pixel NCE losses + gradient w.r.t. the un-normalised features F (contrast_train.py:261-334).
 // One wave = 64 pixels.  Phase A, one lane per pixel: the 21+21 similarities in registers -> the three InfoNCE
 // terms and d(loss)/d(similarity) (44 values, written to the wave's LDS slab).  Phase B, exact-f32 MFMA:
@@ -782,7 +885,7 @@ extern "C" int wseg_select_kth(const float* vals, int rows, int n, int k, int la
   const int gx = std::min(256, (n + 2047) / 2048);
   for (int shift = 24; shift >= 0; shift -= 8) {
     hipLaunchKernelGGL(select_hist_kernel, dim3(gx, rows), dim3(256), 0, ST, vals, n, use_abs, state, hist, shift);
-    hipLaunchKernelGGL(select_scan_kernel, dim3((rows + 63) / 64), dim3(64), 0, ST, state, hist, shift, rows);
+    hipLaunchKernelGGL(select_scan_kernel, dim3(rows), dim3(64), 0, ST, state, hist, shift, rows);
   }
   (void)hipMemsetAsync(res, 0, sizeof(float) * 4 * rows, ST);
   hipLaunchKernelGGL(select_sum_kernel, dim3(gx, rows), dim3(256), 0, ST, vals, n, use_abs, largest, relu_vals, state, res);
@@ -885,6 +988,19 @@ extern "C" int wseg_intra_weights(const int* y, const float* S_own, const float*
   WSEG_CHECK(y && S_own && w && (rkey || rand_flag) && P > 0 && P <= 8192, "intra_weights: needs 0 < P <= 8192 (got %d)", P);
   int P2 = 1; while (P2 < P) P2 <<= 1;
   hipLaunchKernelGGL(intra_weights_kernel, dim3(1), dim3(1024), (size_t)P2 * 8, ST, y, S_own, rkey, rand_flag, w, P);
+  WSEG_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int wseg_intra_pack(const int* y, const float* S_own, const float* rkey, float* rec, int P, void* stream) {
+  WSEG_CHECK(y && S_own && rkey && rec && P > 0, "intra_pack: bad arguments");
+  hipLaunchKernelGGL(intra_pack_kernel, GRID1(P), 0, ST, y, S_own, rkey, rec, P);
+  WSEG_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int wseg_intra_weights_global(const float* rec, float* w, int P, int ranks, int own_rank, float scale, long rank_stride, void* stream) {
+  WSEG_CHECK(rec && w && P > 0 && ranks > 0 && own_rank >= 0 && own_rank < ranks && (long)P * ranks < (1L << 24) && rank_stride >= 3L * P,
+             "intra_weights_global: bad arguments (P=%d ranks=%d own=%d)", P, ranks, own_rank);
+  hipLaunchKernelGGL(intra_weights_global_kernel, dim3(1), dim3(1024), 0, ST, rec, w, P, ranks, own_rank, scale, rank_stride);
   WSEG_LAUNCH_CHECK();
   return 0;
 }

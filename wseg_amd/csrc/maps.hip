@@ -172,23 +172,29 @@ __global__ void resize_adjoint_ones_kernel(float* __restrict__ wvec, int h, int 
   wvec[y] = acc;
 }
 
-// ---- backward of one plane into d_low[pl] ([h][w], written, not accumulated).  One workgroup per plane:
+// ---- backward of one plane into d_low[pl] ([h][w], ACCUMULATED with float atomics: the host zeroes it).  A plane is
+// split over `chunks` workgroups (ranges of the OS x OS outputs and of the S x S pixels); every term is linear, so
+// each workgroup scatters its own share — including its share of the max / min routes:
 //   (1) max_norm + S->OS resize backward of G (label-gated), with the max / min gradient routes;
-//   (2) plane_bias[pl] * wy[y] * wx[x]: the GAP (classification) gradient, a constant over the upsampled plane;
+//   (2) plane_bias[pl] * wy[y] * wx[x]: the GAP (classification) gradient, a constant over the upsampled plane (chunk 0);
 //   (3) min-pool selection (rv map only, q != nullptr): pixels among the k smallest with q > 0 whose arg channel is
 //       this plane send coef * L.
-// Hi-res gradients are scattered to their 4 low-res taps in an LDS image of the plane (LDS float atomics).
+// Hi-res gradients are scattered to their 4 low-res taps in an LDS image of the plane (LDS float atomics), which is
+// added to d_low once at the end.
 __global__ __launch_bounds__(256) void up_maps_bwd_kernel(const float* __restrict__ G, const float* __restrict__ low, const float* __restrict__ stats,
                                                          const float* __restrict__ label20, const float* __restrict__ plane_bias,
                                                          const float* __restrict__ wvec_y, const float* __restrict__ wvec_x,
                                                          const float* __restrict__ q, const unsigned char* __restrict__ argc,
                                                          const float* __restrict__ res, int k, float coef,
-                                                         float* __restrict__ d_low, int h, int w, int S, int OS) {
+                                                         float* __restrict__ d_low, int h, int w, int S, int OS, int chunks) {
   extern __shared__ float dl[];                    // [h*w] gradient image
   __shared__ float red[4];
-  const int pl = blockIdx.x, tid = threadIdx.x;
+  const int pl = blockIdx.x / chunks, ck = blockIdx.x - pl * chunks, tid = threadIdx.x;
   const int c = pl % 21; const int n = pl / 21;
   const float L = c == 0 ? 1.f : label20[n * 20 + c - 1];
+  const float bias = (plane_bias && ck == 0) ? plane_bias[pl] : 0.f;
+  const bool do_norm = L != 0.f && G != nullptr, do_sel = q != nullptr && c >= 1 && L != 0.f;
+  if (!do_norm && !do_sel && bias == 0.f) return;  // (workgroup-uniform)
   const float* p = low + (size_t)pl * h * w;
   const float sy = ac_scale(h, S), sx = ac_scale(w, S);
   for (int i = tid; i < h * w; i += 256) dl[i] = 0.f;
@@ -201,13 +207,15 @@ __global__ __launch_bounds__(256) void up_maps_bwd_kernel(const float* __restric
     atomicAdd(&dl[y1 * w + x0], t * fy * (1.f - fx));
     atomicAdd(&dl[y1 * w + x1], t * fy * fx);
   };
-  if (L != 0.f && G != nullptr) {
+  if (do_norm) {
     const float mx = stats[(size_t)pl * 6 + 0], mn = stats[(size_t)pl * 6 + 1];
     const float invD = 1.f / (mx - mn + 1e-5f);
     const float sc = ac_scale(S, OS);
     const float* g = G + (size_t)pl * OS * OS;
+    const int per = (OS * OS + chunks - 1) / chunks;
+    const int o_end = min(OS * OS, (ck + 1) * per);
     float A = 0.f, B = 0.f;
-    for (int o = tid; o < OS * OS; o += 256) {
+    for (int o = ck * per + tid; o < o_end; o += 256) {
       const float go = g[o] * L;
       if (go == 0.f) continue;
       const int oy = o / OS, ox = o - oy * OS;
@@ -235,31 +243,45 @@ __global__ __launch_bounds__(256) void up_maps_bwd_kernel(const float* __restric
     if (tid == 0) {
       const int imx = __float_as_int(stats[(size_t)pl * 6 + 3]), imn = __float_as_int(stats[(size_t)pl * 6 + 4]);
       const int ymx = imx / S, xmx = imx - ymx * S, ymn = imn / S, xmn = imn - ymn * S;
-      if (up_at(p, h, w, sy, sx, ymx, xmx) > 0.f) scatter(ymx, xmx, -At);          // d/d mx
+      if (up_at(p, h, w, sy, sx, ymx, xmx) > 0.f) scatter(ymx, xmx, -At);          // d/d mx (this chunk's share)
       if (up_at(p, h, w, sy, sx, ymn, xmn) > 0.f) scatter(ymn, xmn, At - Bt);      // d/d mn
     }
   }
-  if (q != nullptr && c >= 1 && L != 0.f) {
+  if (do_sel) {
     const float thr = res[n * 4 + 0];
     const float ce = res[n * 4 + 3];
     const float wtie = ce > 0.f ? ((float)k - res[n * 4 + 2]) / ce : 0.f;
     const float* qn = q + (size_t)n * S * S;
     const unsigned char* an = argc + (size_t)n * S * S;
     const float val = coef * L;
-    for (int i = tid; i < S * S; i += 256) {
-      if (an[i] != (unsigned char)c) continue;
-      const float v = qn[i];
+    const int npix = S * S;
+    const int per = ((npix + chunks - 1) / chunks + 3) & ~3;
+    const int i_end = min(npix, (ck + 1) * per);
+    auto one = [&](int i, unsigned char ac, float v) {
+      if (ac != (unsigned char)c) return;
       float wsel = 0.f;
       if (v < thr) wsel = 1.f; else if (v == thr) wsel = wtie;
       if (wsel > 0.f && v > 0.f) { const int oy = i / S; scatter(oy, i - oy * S, wsel * val); }
+    };
+    if ((npix & 3) == 0) {                          // 4 pixels per lane per iteration: one 4-B and one 16-B load
+      for (int i = ck * per + tid * 4; i < i_end; i += 1024) {
+        const unsigned a4 = *reinterpret_cast<const unsigned*>(an + i);
+        const unsigned cc = (unsigned)c;
+        if (((a4 & 255u) != cc) && (((a4 >> 8) & 255u) != cc) && (((a4 >> 16) & 255u) != cc) && ((a4 >> 24) != cc)) continue;
+        const float4 v4 = *reinterpret_cast<const float4*>(qn + i);
+        one(i, (unsigned char)(a4 & 255u), v4.x); one(i + 1, (unsigned char)((a4 >> 8) & 255u), v4.y);
+        one(i + 2, (unsigned char)((a4 >> 16) & 255u), v4.z); one(i + 3, (unsigned char)(a4 >> 24), v4.w);
+      }
+    } else {
+      for (int i = ck * per + tid; i < i_end; i += 256) one(i, an[i], qn[i]);
     }
   }
   __syncthreads();
-  const float bias = plane_bias ? plane_bias[pl] : 0.f;
   float* o = d_low + (size_t)pl * h * w;
   for (int i = tid; i < h * w; i += 256) {
     const int y = i / w;
-    o[i] = dl[i] + (bias != 0.f ? bias * wvec_y[y] * wvec_x[i - y * w] : 0.f);
+    const float v = dl[i] + (bias != 0.f ? bias * wvec_y[y] * wvec_x[i - y * w] : 0.f);
+    if (v != 0.f) atomicAdd(&o[i], v);
   }
 }
 
@@ -314,8 +336,10 @@ extern "C" int wseg_up_maps_backward(const float* G, const float* low, const flo
   WSEG_CHECK((size_t)h * w * 4 <= 60000, "up_maps_backward: low-res plane %dx%d does not fit the LDS image", h, w);
   WSEG_CHECK(plane_bias == nullptr || (wvec_y && wvec_x), "up_maps_backward: plane_bias needs the adjoint-of-ones vectors");
   WSEG_CHECK(q == nullptr || (argc && res), "up_maps_backward: q needs argc and res");
-  hipLaunchKernelGGL(up_maps_bwd_kernel, dim3((unsigned)(N * 21)), dim3(256), (size_t)h * w * 4, ST, G, low, stats, label20, plane_bias, wvec_y, wvec_x,
-                     q, argc, res, k, coef, d_low, h, w, S, OS);
+  (void)hipMemsetAsync(d_low, 0, sizeof(float) * (size_t)N * 21 * h * w, ST);
+  const int chunks = std::max(1, std::min(16, (S * S) / 8192));
+  hipLaunchKernelGGL(up_maps_bwd_kernel, dim3((unsigned)(N * 21 * chunks)), dim3(256), (size_t)h * w * 4, ST, G, low, stats, label20, plane_bias,
+                     wvec_y, wvec_x, q, argc, res, k, coef, d_low, h, w, S, OS, chunks);
   WSEG_LAUNCH_CHECK();
   return 0;
 }

@@ -35,6 +35,7 @@ class Engine:
         self.injected_masks = None
         self._order = None
         self.flat_w_version = 0             # bumped by the fused SGD step (raw kernel writes)
+        self.block_done_hook = None         # called with the block name when all of its weight gradients are enqueued
 
     # ------------------------------------------------------------------ parameters
     def conv_param(self, name):
@@ -88,6 +89,21 @@ class Engine:
             p.data = p.data.to(device).contiguous(memory_format=torch.channels_last)
         self.flat_w, self.flat_g = flat_w, flat_g
         self.packs = None
+
+    def grad_buckets(self, after=("b7", "b5", "b4", "b3")):
+        """Contiguous slices of flat_g in the order backward completes them: {block name: (begin, end)} — the slice is
+        final once that block's weight gradients are enqueued (flat order = forward order; the heads sit behind b7)."""
+        firsts = {}
+        for b in arch.BLOCKS:
+            if b[0] in arch.FROZEN_BLOCKS:
+                continue
+            firsts[b[0]] = min(self.offsets[c[0]][0] for c in arch.block_convs(b))
+        out, end = {}, self.flat_g.numel()
+        for name in after:
+            out[name] = (firsts[name], end)
+            end = firsts[name]
+        assert end == 0, "the last bucket must reach the start of the flat buffer"
+        return out
 
     def grad_view(self, name):
         off, n = self.offsets[name]
@@ -152,6 +168,23 @@ class Engine:
             mirror = self.flat_wb
         else:
             mirror = self.flat_w
+        # transposed (dgrad) packs [IC][T][OC]: ONE flat buffer, ONE launch over all layers (same offsets as flat_w)
+        if (getattr(self, "flat_wt", None) is None or self.flat_wt.dtype != tdt or self.flat_wt.device != device
+                or self.flat_wt.numel() != self.flat_w.numel()):
+            self.flat_wt = torch.empty(self.flat_w.numel(), device=device, dtype=tdt)
+            rows, tiles = [], 0
+            for b in arch.BLOCKS:
+                if b[0] in arch.FROZEN_BLOCKS:
+                    continue
+                for (cname, ci, co, k, s, d) in arch.block_convs(b):
+                    if cname in no_dgrad:
+                        continue
+                    off, n = self.offsets[cname]
+                    rows.append([tiles, off, off, co, k * k, ci])
+                    tiles += ((co + 31) // 32) * ((ci + 31) // 32) * k * k
+            self._wt_table = torch.tensor(rows, dtype=torch.int64, device=device)
+            self._wt_tiles = tiles
+        L.pack_transposed_batch(self.flat_w, self.flat_wt, self._wt_table, self._wt_table.shape[0], self._wt_tiles, dt)
         for b in arch.BLOCKS:
             if b[0] in arch.FROZEN_BLOCKS:
                 continue
@@ -160,9 +193,7 @@ class Engine:
                 off, n = self.offsets[cname]
                 P["w"][cname] = mirror[off:off + n].view(co, T, ci)
                 if cname not in no_dgrad:
-                    wt = torch.empty(ci, T, co, device=device, dtype=tdt)
-                    L.pack_weights(self.flat_w[off:off + n], None, wt, co, T, ci, co, ci, dt)
-                    P["wt"][cname] = wt
+                    P["wt"][cname] = self.flat_wt[off:off + n].view(ci, T, co)
         # fused head: rows [fc_proj | fc8 | 0]; its transposed pack is made from the two f32 masters directly
         wh = torch.zeros(HEAD_LD, 1, 4096, device=device, dtype=tdt)
         wht = torch.zeros(4096, 1, HEAD_LD, device=device, dtype=tdt)
@@ -185,18 +216,30 @@ class Engine:
         return P
 
     # ------------------------------------------------------------------ dropout
-    def _masks(self, n, device):
+    MASK_SPECS = (("b6.dropout_2b1", 512, 0.3), ("b6.dropout_2b2", 1024, 0.3),
+                  ("b7.dropout_2b1", 1024, 0.5), ("b7.dropout_2b2", 2048, 0.5), ("dropout7", 4096, 0.5))
+
+    def _masks(self, n, views, device):
+        """Dropout2d scales [views*n, C] per dropout site (rows of view 1, then view 2): injected (parity tests) or drawn
+        on the device — one uniform draw + one kernel for all five sites."""
         net = self.net
         if not net.training:
             return None
         if self.injected_masks:
-            m = self.injected_masks.pop(0)
-            return {k: v.to(device=device, dtype=torch.float32).contiguous() for k, v in m.items()}
-        out = {}
-        for key, (c, p) in (("b6.dropout_2b1", (512, 0.3)), ("b6.dropout_2b2", (1024, 0.3)),
-                            ("b7.dropout_2b1", (1024, 0.5)), ("b7.dropout_2b2", (2048, 0.5)),
-                            ("dropout7", (4096, 0.5))):
-            out[key] = (torch.rand(n, c, device=device) >= p).float().div_(1.0 - p)
+            per_view = []
+            for _ in range(views):
+                m = self.injected_masks.pop(0)
+                per_view.append({k: v.to(device=device, dtype=torch.float32) for k, v in m.items()})
+            return {k: torch.cat([m[k] for m in per_view], dim=0).contiguous() for k in per_view[0]}
+        rows = views * n
+        total = sum(c for _, c, _ in self.MASK_SPECS)
+        u = torch.rand(rows * total, device=device)
+        flat = torch.empty_like(u)
+        L.dropout_scale(u, flat, rows * (512 + 1024), 0.3, 0.5)          # the two b6 sites (p = 0.3) come first
+        out, off = {}, 0
+        for key, c, _p in self.MASK_SPECS:
+            out[key] = flat[off:off + rows * c].view(rows, c)
+            off += rows * c
         return out
 
     # ------------------------------------------------------------------ forward
@@ -225,10 +268,7 @@ class Engine:
         P = self.ensure_packs(dev, dt)
         N = xs[0].shape[0]
         assert all(x.shape[0] == N for x in xs)
-        per_view_masks = [self._masks(N, dev) for _ in range(V)]
-        masks = None
-        if per_view_masks[0] is not None:
-            masks = {k: torch.cat([m[k] for m in per_view_masks], dim=0).contiguous() for k in per_view_masks[0]}
+        masks = self._masks(N, V, dev)
         S = {"masks": masks, "dims": {}, "N": N, "V": V, "dt": dt, "xs": xs, "lowres": lowres}
 
         def rows_of(dims):
@@ -505,6 +545,8 @@ class Engine:
                 if not same:
                     wgrad(name + ".conv_branch1", sv["t"], D, cin, cout, 1, stride, 1, din, dout)
                 if first_trainable:
+                    if self.block_done_hook is not None:
+                        self.block_done_hook(name)
                     break
                 Din = E(Mi, cin)
                 if same:
@@ -514,6 +556,8 @@ class Engine:
                     dgrad(D, name + ".conv_branch1", tmp, cin, cout, 1, stride, 1, din, dout)
                     dgrad(du, name + ".conv_branch2a", Din, cin, mid, 3, stride, fd, din, dout, epi=1, scale=sa, mask=sv["t"], r_pre=tmp)
                 D = Din
+                if self.block_done_hook is not None:
+                    self.block_done_hook(name)
             else:
                 c4, c2 = cout // 4, cout // 2
                 s1, _ = P["bn"][name + ".bn_branch2b1"]
@@ -533,6 +577,8 @@ class Engine:
                 Din = E(Mi, cin)
                 dgrad(du1, name + ".conv_branch2a", Din, cin, c4, 1, stride, 1, din, dout, epi=1, scale=sa, mask=sv["t"], r_pre=tmp)
                 D = Din
+                if self.block_done_hook is not None:
+                    self.block_done_hook(name)
         if wstream is not None:
             main.wait_stream(wstream)
             keep.clear()

@@ -7,8 +7,9 @@ combination of a handful of device scalars.  No autograd graph is built.
 
 Global-batch semantics under data parallelism: the per-class top-32 prototype
 candidates (value + feature row) of every rank are all-gathered and merged, so every rank holds the
-prototypes the reference would compute over the whole batch.  Hard-pixel sampling (contrast_train.py
-:302-331) is done per rank (documented deviation: the reference samples over the gathered batch).
+prototypes the reference would compute over the whole batch; hard-pixel sampling (contrast_train.py
+:302-331) exchanges one {label, similarity, random key} record per pixel, and every rank finds the same
+global per-class order statistics (csrc/loss.hip intra_weights_global).
 """
 import os
 
@@ -198,12 +199,29 @@ def step(model, img1, img2, label20, bg_threshold=0.20, rng=None, rng_parity=Fal
         v.fn, v.nrm = _f32(P, 128, dev=dev), _f32(P, dev=dev)
         v.S_own, v.S_oth = _f32(P, 21, dev=dev), _f32(P, 21, dev=dev)
         L.nce_sims(v.F, v.protos, o.protos, v.fn, v.nrm, v.S_own, v.S_oth, P)
-    for v in views:                                        # view 1 fully before view 2 (RNG order of the reference)
-        v.w_intra = _f32(P, dev=dev)
-        if rng_parity:
-            L.intra_weights(v.y, v.S_own, None, _rand_flags(v.y, rng, P), v.w_intra, P)
-        else:
-            L.intra_weights(v.y, v.S_own, torch.rand(P, device=dev), None, v.w_intra, P)
+    if world > 1 or os.environ.get("WSEG_INTRA_GLOBAL", "0") == "1":
+        # Hard-pixel sampling over the GLOBAL batch (the reference samples on the gathered batch): one
+        # all-gather of {label, own-class similarity, random key} per pixel (96 KB per rank for both views); every rank
+        # then finds the same global per-class order statistics and keeps the weights of its own pixels, scaled by
+        # `world` because the gradient all-reduce averages.
+        rank = dist.get_rank() if world > 1 else 0
+        rec = _f32(2, 3, P, dev=dev)
+        for vi, v in enumerate(views):
+            L.intra_pack(v.y, v.S_own, torch.rand(P, device=dev), rec[vi], P)
+        grec = rec
+        if world > 1:
+            grec = _f32(world, 2, 3, P, dev=dev)
+            dist.all_gather_into_tensor(grec.view(world * 6, P), rec.view(6, P))
+        for vi, v in enumerate(views):
+            v.w_intra = _f32(P, dev=dev)
+            L.intra_weights_global(grec.view(-1)[vi * 3 * P:], v.w_intra, P, world, rank, float(world), 6 * P)
+    else:
+        for v in views:                                    # view 1 fully before view 2 (RNG order of the reference)
+            v.w_intra = _f32(P, dev=dev)
+            if rng_parity:
+                L.intra_weights(v.y, v.S_own, None, _rand_flags(v.y, rng, P), v.w_intra, P)
+            else:
+                L.intra_weights(v.y, v.S_own, torch.rand(P, device=dev), None, v.w_intra, P)
     for v, o in ((v1, v2), (v2, v1)):
         v.dF = _f32(P, 128, dev=dev)
         L.nce_loss_grad(v.fn, v.nrm, v.S_own, v.S_oth, v.y, o.y, v.w_intra, v.protos, o.protos, v.dF, acc[4:7], P,

@@ -5,6 +5,7 @@ two Net forwards -> loss -> backward -> gradient all-reduce (one process per GPU
 PolyOptimizer step.  Returns the 8 logged scalars as device tensors (no host sync; the reference
 syncs 8x per step with .item(), :401-408).
 """
+import os
 import random as _random
 
 import torch
@@ -33,6 +34,21 @@ class Trainer:
         self.loss_impl = loss_impl
         self.bg_topk_idx = bg_topk_idx
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self._pending = []
+        if self.world > 1 and loss_impl == "hip" and os.environ.get("WSEG_BUCKETS", "1") != "0":   # (one joint backward)
+            # Gradient all-reduce overlapped with backward: the flat gradient buffer completes back to front, so each
+            # bucket (b7 + heads, b5..b6, b4*, b3*: 154 / 143 / 109 / 13 MB) is reduced as soon as its last weight
+            # gradient is enqueued — RCCL runs on its own stream behind those kernels while dgrad/wgrad continue.
+            model._engine.block_done_hook = self._on_block_done
+
+    def _on_block_done(self, name):
+        eng = self.model._engine
+        buckets = getattr(self, "_buckets", None)
+        if buckets is None:
+            buckets = self._buckets = eng.grad_buckets()
+        if name in buckets:
+            lo, hi = buckets[name]
+            self._pending.append(dist.all_reduce(eng.flat_g[lo:hi], async_op=True))
 
     def step(self, img1, label20):
         if not img1.is_cuda:
@@ -52,8 +68,12 @@ class Trainer:
             losses = loss_hip.step(model, img1, img2, label20, self.bg_threshold, self.rng, self.rng_parity,
                                    self.bg_topk_idx)
         if self.world > 1:
-            eng = model._engine
-            dist.all_reduce(eng.flat_g)                     # RCCL over xGMI; averaged by grad_scale below
+            if self._pending:                               # bucketed all-reduces launched during backward
+                for work in self._pending:
+                    work.wait()
+                self._pending = []
+            else:
+                dist.all_reduce(model._engine.flat_g)       # RCCL over xGMI; averaged by grad_scale below
             opt.wseg_grad_scale = 1.0 / self.world
         opt.step()
         return {k: v.detach() for k, v in losses.items()}
