@@ -280,47 +280,76 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pipe_kernel(const Args a) {
   const char* X = reinterpret_cast<const char*>(d.x);
   const char* DY = reinterpret_cast<const char*>(d.dy);
 
-  // staging: thread -> rows r0 = tid>>4 and r0+32 of every half-tile, physical 16-B chunk tid&15
+  // staging: thread -> rows r0 = tid>>4 and r0+32 of every half-tile, physical 16-B chunk tid&15.
+  // All per-K-tile address work is INCREMENTAL (this loop is VALU-sensitive: 64 MFMAs per wave per K-tile leave
+  // ~250 issue slots): dY pointers advance by a constant; the X pixel coordinates (n, oy, ox) advance by 64 rows
+  // with one add / compare / subtract each instead of three integer divisions per row.
   const int pch = tid & 15;
-  int rr[2], lc[2];
+  const char* zsrc = zero + (lane & 15) * 16;
+  int lc[2];
+  const char* ybase[2];                              // dY source of the NEXT Y tile (row rr[k], chunk lc[k], half 0)
+  int my[2];                                         // its pixel row
+  int xm[2], xoy[2], xox[2], xbase[2];               // NEXT X tile: pixel row, output coordinates, first input row of the image
+  const int M1 = d.N * d.OH * d.OW;
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
-    rr[k] = (tid >> 4) + 32 * k;
-    const int sw = (rr[k] & 3) | (((rr[k] >> 3) & 1) << 2);
+    const int rr = (tid >> 4) + 32 * k;
+    const int sw = (rr & 3) | (((rr >> 3) & 1) << 2);
     lc[k] = (((pch >> 1) ^ sw) << 1) | (pch & 1);
+    my[k] = m_begin + rr;
+    ybase[k] = DY + ((size_t)my[k] * d.ld_dy + oc0 + lc[k] * 8) * 2;
+    xm[k] = m_begin + rr;
+    const wseg_rowgeo rg = wseg_decode_row(d, min(xm[k], a.M - 1));
+    xoy[k] = rg.oy; xox[k] = rg.ox; xbase[k] = (int)rg.in_base;
   }
-  const char* xrow[2];                               // source pixel row of the X tile being issued (or nullptr)
-  auto x_prepare = [&](int kt) {                     // call once per X tile, before its two half issues
+  const size_t ystep = (size_t)PK * d.ld_dy * 2;
+  const bool yok[2][2] = {{oc0 + lc[0] * 8 < d.OC, oc0 + 128 + lc[0] * 8 < d.OC}, {oc0 + lc[1] * 8 < d.OC, oc0 + 128 + lc[1] * 8 < d.OC}};
+  const bool xok[2][2] = {{ic0 + lc[0] * 8 < d.IC, ic0 + 128 + lc[0] * 8 < d.IC}, {ic0 + lc[1] * 8 < d.IC, ic0 + 128 + lc[1] * 8 < d.IC}};
+  const char* xrow[2];                               // source pixel row (chunk lc[k], half 0) of the X tile being issued, or nullptr
+  auto x_prepare = [&]() {                           // call once per X tile, before its two half issues; advances to the next tile
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-      const int m = m_begin + kt * PK + rr[k];
+      const bool s2 = d.OH2 != 0 && xm[k] >= M1;
+      const int OHs = s2 ? d.OH2 : d.OH, OWs = s2 ? d.OW2 : d.OW, IHs = s2 ? d.IH2 : d.IH, IWs = s2 ? d.IW2 : d.IW;
       xrow[k] = nullptr;
-      if (m < m_end) {
-        const wseg_rowgeo rg = wseg_decode_row(d, m);
-        const int iy = rg.oy * d.stride + ky * d.dil - d.pad;
-        const int ix = rg.ox * d.stride + kx * d.dil - d.pad;
-        if (iy >= 0 && iy < rg.IH && ix >= 0 && ix < rg.IW)
-          xrow[k] = X + (size_t)(rg.in_base + (long)iy * rg.IW + ix) * d.ld_x * 2;
+      if (xm[k] < m_end) {
+        const int iy = xoy[k] * d.stride + ky * d.dil - d.pad;
+        const int ix = xox[k] * d.stride + kx * d.dil - d.pad;
+        if (iy >= 0 && iy < IHs && ix >= 0 && ix < IWs)
+          xrow[k] = X + ((size_t)(xbase[k] + iy * IWs + ix) * d.ld_x + ic0 + lc[k] * 8) * 2;
       }
+      // advance 64 pixel rows
+      const int mn = xm[k] + PK;
+      if (d.OH2 != 0 && xm[k] < M1 && mn >= M1) {     // crosses into the second segment: decode afresh (rare)
+        const wseg_rowgeo rg = wseg_decode_row(d, min(mn, a.M - 1));
+        xoy[k] = rg.oy; xox[k] = rg.ox; xbase[k] = (int)rg.in_base;
+      } else {
+        int ox = xox[k] + PK, oy = xoy[k], bs = xbase[k];
+        while (ox >= OWs) { ox -= OWs; ++oy; }
+        while (oy >= OHs) { oy -= OHs; bs += IHs * IWs; }
+        xox[k] = ox; xoy[k] = oy; xbase[k] = bs;
+      }
+      xm[k] = mn;
     }
   };
   auto issue_x = [&](int h, int buf) {
     char* dst = smem + buf * TILE + (2 + h) * HALF + wid * 1024;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-      const int ch = ic0 + h * 128 + lc[k] * 8;
-      const char* p = (xrow[k] && ch < d.IC) ? xrow[k] + (size_t)ch * 2 : zero + (lane & 15) * 16;
+      const char* p = (xrow[k] && xok[k][h]) ? xrow[k] + h * 256 : zsrc;
       glds16(p, dst + k * 8192);
     }
   };
-  auto issue_y = [&](int h, int buf, int kt) {
+  auto issue_y = [&](int h, int buf) {               // half h of the NEXT Y tile; h == 1 advances to the following tile
     char* dst = smem + buf * TILE + h * HALF + wid * 1024;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-      const int m = m_begin + kt * PK + rr[k];
-      const int ch = oc0 + h * 128 + lc[k] * 8;
-      const char* p = (m < m_end && ch < d.OC) ? DY + ((size_t)m * d.ld_dy + ch) * 2 : zero + (lane & 15) * 16;
+      const char* p = (my[k] < m_end && yok[k][h]) ? ybase[k] + h * 256 : zsrc;
       glds16(p, dst + k * 8192);
+    }
+    if (h == 1) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) { ybase[k] += ystep; my[k] += PK; }
     }
   };
 
@@ -347,9 +376,9 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pipe_kernel(const Args a) {
 
   const int nt = (m_end - m_begin + PK - 1) / PK;
   // prologue: tile 0 entirely + the X halves of tile 1
-  issue_y(0, 0, 0); issue_y(1, 0, 0);
-  x_prepare(0); issue_x(0, 0); issue_x(1, 0);
-  if (nt > 1) { x_prepare(1); issue_x(0, 1); issue_x(1, 1); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+  issue_y(0, 0); issue_y(1, 0);
+  x_prepare(); issue_x(0, 0); issue_x(1, 0);
+  if (nt > 1) { x_prepare(); issue_x(0, 1); issue_x(1, 1); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   asm volatile("s_barrier" ::: "memory");
 
@@ -387,21 +416,21 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pipe_kernel(const Args a) {
     const unsigned bbase = lds0 + b * TILE + (2 + (wc >> 1)) * HALF;
     // ---- p1: quadrant (0,0)
     LOAD_A(0) LOAD_B(0, vb0)
-    if (u + 1 < nt) issue_y(0, b ^ 1, u + 1);
+    if (u + 1 < nt) issue_y(0, b ^ 1);
     WAIT_LDS();
     PACK_A() PACK_B(b0, vb0)
     MFMA_Q(0, 0, b0);
     asm volatile("s_barrier" ::: "memory");
     // ---- p2: quadrant (0,1)
     LOAD_B(1, vb1)
-    if (u + 1 < nt) issue_y(1, b ^ 1, u + 1);
+    if (u + 1 < nt) issue_y(1, b ^ 1);
     WAIT_LDS();
     PACK_B(b1, vb1)
     MFMA_Q(0, 1, b1);
     asm volatile("s_barrier" ::: "memory");
     // ---- p3: quadrant (1,1)
     LOAD_A(1)
-    if (u + 2 < nt) { x_prepare(u + 2); issue_x(0, b); }
+    if (u + 2 < nt) { x_prepare(); issue_x(0, b); }
     WAIT_LDS();
     PACK_A()
     MFMA_Q(1, 1, b1);
