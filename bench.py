@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--loss", default=os.environ.get("WSEG_LOSS", "hip"), choices=["hip", "aten"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--event-stride", type=int, default=5, help="bracket every k-th conv launch with HIP events (rotating)")
     ap.add_argument("--lr", type=float, default=1e-5,
                     help="base lr; the reference's 0.01 makes the RANDOM procedural weights diverge within 2 steps "
                          "(measured, scripts/debug_step.py), so the bench steps with a small lr — same kernels, same work")
@@ -112,10 +113,15 @@ def main():
 
     for _ in range(a.warmup):
         trainer.step(img, lab)
+    # HIP events around the conv_igemm launches, live in the timed region, on the launch stream.  An event pair costs
+    # ~10 us of stream time, so launch i of step s is bracketed only when (i + s) % stride == 0: every launch index
+    # is sampled steps/stride times while the timed region slows by ~0.2 ms/step instead of ~1 ms.
     L.PROFILE = []
+    L.PROFILE_STRIDE = max(1, min(a.event_stride, a.steps))
     barrier()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for it in range(a.steps):
+        L.profile_begin_step(it)
         losses = trainer.step(img, lab)
     barrier()
     dt = time.perf_counter() - t0
@@ -130,9 +136,13 @@ def main():
     if rank == 0:
         # dominant kernel: the implicit-GEMM conv (fwd + dgrad launches), timed with HIP events on the
         # launch stream during the timed region
-        tot_ms = sum(p_[0].elapsed_time(p_[1]) for p_ in prof)
-        tot_fl = sum(p_[2] for p_ in prof)
-        n_launch = max(1, len(prof))
+        per_idx = {}                                           # launch index within a step -> [sum ms, samples, flops]
+        for p_ in prof:
+            e = per_idx.setdefault(p_[4], [0.0, 0, p_[2]])
+            e[0] += p_[0].elapsed_time(p_[1]); e[1] += 1
+        tot_ms = sum(e[0] / e[1] for e in per_idx.values()) * a.steps     # = one step's launches, averaged over their samples
+        tot_fl = sum(e[2] for e in per_idx.values()) * a.steps
+        n_launch = max(1, len(per_idx)) * a.steps
         peak = PEAK_BF16_TFLOPS if a.precision == "bf16" else PEAK_F32_TFLOPS
         achieved = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
         traffic, traffic_src = None, None
@@ -145,7 +155,7 @@ def main():
             pass
         roof = {"bound": "mfma", "kernel": "conv_igemm_kernel", "achieved": round(achieved, 1), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
-                "launches_per_step": n_launch // a.steps,
+                "launches_per_step": n_launch // a.steps, "event_samples": len(prof),
                 "avg_launch_ms": round(tot_ms / n_launch, 4), "avg_launch_gflop": round(tot_fl / n_launch / 1e9, 2),
                 "whole_step_frac": round(conv_flops_model() * a.batch / (ms * 1e-3) / 1e12 / peak, 4)}
         line = {"metric": "training images/sec at B=16x448x448 (contrast_train step)", "value": round(value, 2),

@@ -220,10 +220,11 @@ int wseg_nce_loss_grad(const float* fn, const float* nrm, const float* S_own, co
 
 /* ---- fused SGD step (tool/torchutils.py:23-33 -> torch.optim.SGD.step) ------------------------
  * One pass over the flat buffers: d = g*grad_scale + wd*p; buf = first ? d : momentum*buf + d;
- * p -= lr*buf.  Segments [begin,end) carry the per-group lr / weight_decay (contrast_train.py:91-96). */
+ * p -= lr*buf.  Segments [begin,end) carry the per-group lr / weight_decay (contrast_train.py:91-96).
+ * bf16_mirror (nullable): also receives the updated weights in bf16 (the next step's forward packs). */
 int wseg_sgd_step(float* params, const float* grads, float* momentum_buf, long numel,
                   const long* seg_begin, const long* seg_end, const float* seg_lr, const float* seg_wd, int nseg,
-                  float momentum, float grad_scale, int first_step, void* stream);
+                  float momentum, float grad_scale, int first_step, void* bf16_mirror, void* stream);
 
 #ifdef __cplusplus
 }

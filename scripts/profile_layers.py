@@ -23,7 +23,7 @@ for _ in range(steps): tr.step(img, lab)
 torch.cuda.synchronize()
 for nm, prof in (("igemm", L.PROFILE), ("wgrad", L.PROFILE_WGRAD)):
     agg = collections.OrderedDict()
-    for (s, e, f, tag) in prof:
+    for (s, e, f, tag, *_rest) in prof:
         a = agg.setdefault(tag, [0, 0.0, 0.0]); a[0] += 1; a[1] += s.elapsed_time(e); a[2] += f
     tot = sum(a[1] for a in agg.values()) / steps
     print(f"== {nm}: {tot:.2f} ms/step, {sum(a[2] for a in agg.values())/steps/1e12:.2f} TFLOP/step")

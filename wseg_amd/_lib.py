@@ -14,6 +14,22 @@ LIB_PATH = os.path.join(_HERE, "libwseg_hip.so")
 F32, BF16 = 0, 1
 PROFILE_WGRAD = None
 PROFILE = None        # set to a list by bench.py to collect (start_event, end_event, flops) per conv launch
+PROFILE_STRIDE = 1    # event-bracket launch i of step s only when (i + s) % stride == 0: an event pair costs ~10 us of
+_profile_idx = 0      # stream time, 81 pairs per step would slow the timed region by ~2 %
+_profile_phase = 0
+
+
+def profile_begin_step(step):
+    """bench.py calls this at the start of every timed step: launch indices restart, the sampling phase rotates."""
+    global _profile_idx, _profile_phase
+    _profile_idx, _profile_phase = 0, step % max(1, PROFILE_STRIDE)
+
+
+def _profile_sample():
+    global _profile_idx
+    i = _profile_idx
+    _profile_idx += 1
+    return (i + _profile_phase) % max(1, PROFILE_STRIDE) == 0, i
 TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16}
 
 
@@ -90,17 +106,18 @@ def conv_igemm(inp, w, out=None, out2=None, *, N, IH, IW, IC, OH, OW, OC, KH, KW
     d.mode, d.epi, d.dtype, d.relu_out2, d.relu_lt, d.bm_hint = mode, epi, dtype_code(inp), relu_out2, relu_lt, bm_hint
     if seg2 is not None:                         # (IH2, IW2, OH2, OW2): second row segment, same N
         d.IH2, d.IW2, d.OH2, d.OW2 = seg2
-    if PROFILE is not None:                      # bench.py: HIP events on the launch stream around this launch
+    sampled, launch_idx = _profile_sample() if PROFILE is not None else (False, 0)
+    if sampled:                                  # bench.py: HIP events on the launch stream around this launch
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
     check(lib.wseg_conv_igemm(C.byref(d), C.c_void_p(stream_ptr())), "wseg_conv_igemm")
-    if PROFILE is not None:
+    if sampled:
         ev1.record()
         pix = N * (OH * OW if mode == 0 else IH * IW)        # algorithmic: the conv's output pixels
         if seg2 is not None:
             pix += N * (seg2[2] * seg2[3] if mode == 0 else seg2[0] * seg2[1])
         PROFILE.append((ev0, ev1, 2.0 * pix * IC * OC * KH * KW,
-                        f"{'fwd' if mode == 0 else 'dgrad'} {IC}->{OC} k{KH} s{stride} d{dil} {OH}x{OW}"))
+                        f"{'fwd' if mode == 0 else 'dgrad'} {IC}->{OC} k{KH} s{stride} d{dil} {OH}x{OW}", launch_idx))
 
 
 def conv_wgrad(x, dy, dw, *, N, IH, IW, IC, OH, OW, OC, KH, KW, stride=1, dil=1, pad=0,
@@ -198,14 +215,14 @@ def pcm_backward(Fh, G, d_cam_rv, cam_rv, den, DN, dFh, N, hw):
     check(lib.wseg_pcm_backward(_v(Fh), _v(G), _v(d_cam_rv), _v(cam_rv), _v(den), _v(DN), _v(dFh), N, hw, _s()), "wseg_pcm_backward")
 
 
-def sgd_step(params, grads, buf, segs, momentum, grad_scale, first_step):
+def sgd_step(params, grads, buf, segs, momentum, grad_scale, first_step, bf16_mirror=None):
     """segs: list of (begin, end, lr, weight_decay) over the flat buffers."""
     n = len(segs)
     LongArr, FloatArr = C.c_long * n, C.c_float * n
     b = LongArr(*[s[0] for s in segs]); e = LongArr(*[s[1] for s in segs])
     lr = FloatArr(*[s[2] for s in segs]); wd = FloatArr(*[s[3] for s in segs])
     check(lib.wseg_sgd_step(_v(params), _v(grads), _v(buf), C.c_long(params.numel()), b, e, lr, wd, n,
-                            C.c_float(momentum), C.c_float(grad_scale), int(first_step), _s()), "wseg_sgd_step")
+                            C.c_float(momentum), C.c_float(grad_scale), int(first_step), _v(bf16_mirror), _s()), "wseg_sgd_step")
 
 
 # ---------------------------------------------------------------------------------------------- loss kernels

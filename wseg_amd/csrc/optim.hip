@@ -13,7 +13,8 @@ constexpr int MAX_SEG = 8;
 struct SegTable { Seg s[MAX_SEG]; int n; };
 
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
-                                                  const SegTable tab, float mom, float gscale, int first, long total4) {
+                                                  const SegTable tab, float mom, float gscale, int first, long total4,
+                                                  bf16_t* __restrict__ mirror) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
     const long e0 = i * 4;
     float lr = 0.f, wd = 0.f;
@@ -35,6 +36,11 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
     }
     reinterpret_cast<float4*>(p)[i] = make_float4(pe[0], pe[1], pe[2], pe[3]);
     reinterpret_cast<float4*>(buf)[i] = make_float4(be[0], be[1], be[2], be[3]);
+    if (mirror) {                                  // bf16 copy of the updated weights (next step's forward packs)
+      const unsigned lo = (unsigned)f32_to_bf16(pe[0]) | ((unsigned)f32_to_bf16(pe[1]) << 16);
+      const unsigned hi = (unsigned)f32_to_bf16(pe[2]) | ((unsigned)f32_to_bf16(pe[3]) << 16);
+      reinterpret_cast<uint2*>(mirror)[i] = make_uint2(lo, hi);
+    }
   }
 }
 
@@ -42,7 +48,7 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
 
 extern "C" int wseg_sgd_step(float* params, const float* grads, float* momentum_buf, long numel,
                              const long* seg_begin, const long* seg_end, const float* seg_lr, const float* seg_wd, int nseg,
-                             float momentum, float grad_scale, int first_step, void* stream) {
+                             float momentum, float grad_scale, int first_step, void* bf16_mirror, void* stream) {
   WSEG_CHECK(params && grads && momentum_buf && numel > 0, "sgd_step: null pointer");
   WSEG_CHECK(nseg >= 1 && nseg <= MAX_SEG, "sgd_step: 1..%d segments", MAX_SEG);
   WSEG_CHECK(numel % 4 == 0, "sgd_step: numel must be a multiple of 4");
@@ -54,7 +60,7 @@ extern "C" int wseg_sgd_step(float* params, const float* grads, float* momentum_
   }
   const long total4 = numel / 4;
   const int blocks = (int)std::min<long>((total4 + 255) / 256, 8192);
-  hipLaunchKernelGGL(sgd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, grads, momentum_buf, tab, momentum, grad_scale, first_step, total4);
+  hipLaunchKernelGGL(sgd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, grads, momentum_buf, tab, momentum, grad_scale, first_step, total4, (bf16_t*)bf16_mirror);
   WSEG_LAUNCH_CHECK();
   return 0;
 }

@@ -35,6 +35,8 @@ class Engine:
         self.injected_masks = None
         self._order = None
         self.flat_w_version = 0             # bumped by the fused SGD step (raw kernel writes)
+        self.flat_wb = None
+        self.flat_wb_version = None
         self.block_done_hook = None         # called with the block name when all of its weight gradients are enqueued
 
     # ------------------------------------------------------------------ parameters
@@ -89,6 +91,11 @@ class Engine:
             p.data = p.data.to(device).contiguous(memory_format=torch.channels_last)
         self.flat_w, self.flat_g = flat_w, flat_g
         self.packs = None
+        self.flat_wb_version = None                          # the bf16 mirror (if any) is stale
+
+    def _mirror_fresh(self, names):
+        """False when a parameter was modified through torch (load_state_dict, manual edits) since the mirror was written."""
+        return getattr(self, "_mirror_pversions", None) == tuple(self.conv_param(n_)._version for n_ in names)
 
     def grad_buckets(self, after=("b7", "b5", "b4", "b3")):
         """Contiguous slices of flat_g in the order backward completes them: {block name: (begin, end)} — the slice is
@@ -164,7 +171,11 @@ class Engine:
         if dt == L.BF16:
             if getattr(self, "flat_wb", None) is None or self.flat_wb.numel() != self.flat_w.numel() or self.flat_wb.device != device:
                 self.flat_wb = torch.empty(self.flat_w.numel(), device=device, dtype=torch.bfloat16)
-            L.to_bf16(self.flat_w, self.flat_wb)
+                self.flat_wb_version = None
+            if self.flat_wb_version != self.flat_w_version or not self._mirror_fresh(names):
+                L.to_bf16(self.flat_w, self.flat_wb)             # (normally the fused SGD step has already written it)
+                self.flat_wb_version = self.flat_w_version
+            self._mirror_pversions = tuple(self.conv_param(n_)._version for n_ in names)
             mirror = self.flat_wb
         else:
             mirror = self.flat_w

@@ -29,13 +29,18 @@ def _side_streams(eng, dev):
     return st
 
 
-def cpu_tie_pattern(P, k):
+def cpu_tie_pattern(P, k, device=None):
     """Q5: the index set torch.topk returns for a fully tied row of length P on the CPU library the
-    reference's CPU path uses.  Data independent; computed once per (P, k)."""
+    reference's CPU path uses.  Data independent; computed once per (P, k) (and uploaded once per device)."""
     key = (P, k)
     if key not in _TIE_CACHE:
         _TIE_CACHE[key] = torch.topk(torch.full((1, P), 0.2), k, dim=-1)[1][0].to(torch.int32)
-    return _TIE_CACHE[key]
+    if device is None:
+        return _TIE_CACHE[key]
+    dkey = (P, k, str(device))
+    if dkey not in _TIE_CACHE:
+        _TIE_CACHE[dkey] = _TIE_CACHE[key].to(device)
+    return _TIE_CACHE[dkey]
 
 
 def _f32(*shape, dev):
@@ -161,45 +166,49 @@ def step(model, img1, img2, label20, bg_threshold=0.20, rng=None, rng_parity=Fal
     # losses then run on their own HIP streams.
     outs, ctx = eng.run_forward([img1, img2], save=True, lowres=True)
     fork = main.record_event()
+    P = N * 256
+    tie_idx = (bg_topk_idx.to(device=dev, dtype=torch.int32) if bg_topk_idx is not None else cpu_tie_pattern(P, 32, dev))
     views = []
-    for img, (cam_low, rvd, _fp, head), vw, st in zip((img1, img2), outs, ctx["views"], side):
+    for img, (cam_low, rvd, _fp, head), vw in zip((img1, img2), outs, ctx["views"]):
         v = _View()
         v.S, v.h, v.w, v.off = img.shape[2], vw["h"], vw["w"], vw["off"]
         v.cam_low, v.rvd, v.head = cam_low, rvd, head
+        views.append(v)
+    v1, v2 = views
+    # per view, on its own stream: map losses (cls, min-pool, max-norm maps), then pseudo-labels + prototype candidates
+    for v, st in zip(views, side):
         st.wait_event(fork)
         with torch.cuda.stream(st):
             _maps_forward(v, label20, acc, N)
-        views.append(v)
-    v1, v2 = views
+            if world == 1:
+                _prototypes(v, label20, bg_threshold, tie_idx, N, world)
     for st in side:
         main.wait_stream(st)
-    # ---- ER + ECR on the 128x128 maps
+    if world > 1:                                           # collectives stay on the main stream, in program order
+        for v in views:
+            _prototypes(v, label20, bg_threshold, tie_idx, N, world)
+    # ---- ER + ECR on the 128x128 maps (both directions of the ECR top-k in ONE 2N-row selection)
     npix = 128 * 128
     er_coef = 1.0 / (N * 20 * npix)
     for v in views:
         v.Gc = _f32(N, 21, 128, 128, dev=dev)
-    dlt1, dlt2 = _f32(N, 21 * npix, dev=dev), _f32(N, 21 * npix, dev=dev)
-    L.er_ecr_prep(v1.c, v2.c, v1.r, v2.r, v1.Gc, v2.Gc, dlt1, dlt2, acc[2:3], N, npix, er_coef)
+    dlt = _f32(2 * N, 21 * npix, dev=dev)
+    L.er_ecr_prep(v1.c, v2.c, v1.r, v2.r, v1.Gc, v2.Gc, dlt[:N], dlt[N:], acc[2:3], N, npix, er_coef)
     K_ecr = int(21 * npix * 0.2)
-    ws = torch.empty(L.select_workspace_bytes(N), device=dev, dtype=torch.uint8)
-    for v, dlt in ((v1, dlt1), (v2, dlt2)):
-        res = _f32(N, 4, dev=dev)
-        L.select_kth(dlt, N, 21 * npix, K_ecr, True, True, False, res, ws)
-        L.select_finish(res, N, K_ecr, False, 1.0 / (N * K_ecr), acc[3:4])
-        v.Gr = _f32(N, 21, 128, 128, dev=dev)
-        L.ecr_backward(dlt, res, v.Gr, N, 21 * npix, K_ecr, 1.0 / (N * K_ecr))
-    for v in views:
-        _maps_backward(v, label20, N)
+    ws = torch.empty(L.select_workspace_bytes(2 * N), device=dev, dtype=torch.uint8)
+    res = _f32(2 * N, 4, dev=dev)
+    L.select_kth(dlt, 2 * N, 21 * npix, K_ecr, True, True, False, res, ws)
+    L.select_finish(res, 2 * N, K_ecr, False, 1.0 / (N * K_ecr), acc[3:4])
+    Gr = _f32(2 * N, 21, 128, 128, dev=dev)
+    L.ecr_backward(dlt, res, Gr, 2 * N, 21 * npix, K_ecr, 1.0 / (N * K_ecr))
+    v1.Gr, v2.Gr = Gr[:N], Gr[N:]
     # ---- pixel-to-prototype contrast at 16x16
-    P = N * 256
-    tie_idx = (bg_topk_idx if bg_topk_idx is not None else cpu_tie_pattern(P, 32)).to(device=dev, dtype=torch.int32)
-    for v in views:
-        _prototypes(v, label20, bg_threshold, tie_idx, N, world)
     for v, o in ((v1, v2), (v2, v1)):
         v.fn, v.nrm = _f32(P, 128, dev=dev), _f32(P, dev=dev)
         v.S_own, v.S_oth = _f32(P, 21, dev=dev), _f32(P, 21, dev=dev)
         L.nce_sims(v.F, v.protos, o.protos, v.fn, v.nrm, v.S_own, v.S_oth, P)
-    if world > 1 or os.environ.get("WSEG_INTRA_GLOBAL", "0") == "1":
+    global_intra = world > 1 or os.environ.get("WSEG_INTRA_GLOBAL", "0") == "1"
+    if global_intra:
         # Hard-pixel sampling over the GLOBAL batch (the reference samples on the gathered batch): one
         # all-gather of {label, own-class similarity, random key} per pixel (96 KB per rank for both views); every rank
         # then finds the same global per-class order statistics and keeps the weights of its own pixels, scaled by
@@ -212,16 +221,24 @@ def step(model, img1, img2, label20, bg_threshold=0.20, rng=None, rng_parity=Fal
         if world > 1:
             grec = _f32(world, 2, 3, P, dev=dev)
             dist.all_gather_into_tensor(grec.view(world * 6, P), rec.view(6, P))
-        for vi, v in enumerate(views):
-            v.w_intra = _f32(P, dev=dev)
-            L.intra_weights_global(grec.view(-1)[vi * 3 * P:], v.w_intra, P, world, rank, float(world), 6 * P)
-    else:
+    elif rng_parity:
         for v in views:                                    # view 1 fully before view 2 (RNG order of the reference)
             v.w_intra = _f32(P, dev=dev)
-            if rng_parity:
-                L.intra_weights(v.y, v.S_own, None, _rand_flags(v.y, rng, P), v.w_intra, P)
-            else:
+            L.intra_weights(v.y, v.S_own, None, _rand_flags(v.y, rng, P), v.w_intra, P)
+    # per view, again on its own stream: hard-pixel weights (a single-workgroup kernel) and the map backward
+    fork2 = main.record_event()
+    for vi, (v, st) in enumerate(zip(views, side)):
+        st.wait_event(fork2)
+        with torch.cuda.stream(st):
+            if global_intra:
+                v.w_intra = _f32(P, dev=dev)
+                L.intra_weights_global(grec.view(-1)[vi * 3 * P:], v.w_intra, P, world, rank, float(world), 6 * P)
+            elif not rng_parity:
+                v.w_intra = _f32(P, dev=dev)
                 L.intra_weights(v.y, v.S_own, torch.rand(P, device=dev), None, v.w_intra, P)
+            _maps_backward(v, label20, N)
+    for st in side:
+        main.wait_stream(st)
     for v, o in ((v1, v2), (v2, v1)):
         v.dF = _f32(P, 128, dev=dev)
         L.nce_loss_grad(v.fn, v.nrm, v.S_own, v.S_oth, v.y, o.y, v.w_intra, v.protos, o.protos, v.dF, acc[4:7], P,

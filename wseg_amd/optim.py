@@ -77,10 +77,15 @@ class PolyOptimizer(torch.optim.SGD):
             if self._flat_buf is None or self._flat_buf.numel() != eng.flat_w.numel() or self._flat_buf.device != eng.flat_w.device:
                 self._flat_buf = torch.empty_like(eng.flat_w)
                 self._flat_first = True
+            mirror = getattr(eng, "flat_wb", None)         # bf16 mode: the fused step refreshes the forward packs' mirror too
+            if mirror is not None and (mirror.numel() != eng.flat_w.numel() or mirror.device != eng.flat_w.device):
+                mirror = None
             L.sgd_step(eng.flat_w, eng.flat_g, self._flat_buf, [(s[0], s[1], s[2], s[3]) for s in segs],
-                       segs[0][4], self.wseg_grad_scale, self._flat_first)
+                       segs[0][4], self.wseg_grad_scale, self._flat_first, mirror)
             self._flat_first = False
             eng.flat_w_version += 1
+            if mirror is not None:
+                eng.flat_wb_version = eng.flat_w_version
         self.global_step += 1
 
     def zero_grad(self, set_to_none=True):
