@@ -241,6 +241,10 @@ def test_conv256_fwd_dgrad(case):
     y128 = torch.empty_like(yg)
     L.conv_igemm(xg, wf, y128, N=N, IH=H, IW=W, IC=IC, OH=OH, OW=OW, OC=OC, KH=k, KW=k, stride=s, dil=d, pad=pad, bm_hint=128)
     assert float((yg.float() - y128.float()).abs().max()) <= 2e-2
+    # row split (full rounds on the 256-tile kernel, remaining rows on the 128-tile kernel): 257 forces it at half the rows
+    ysp = torch.full_like(yg, float("nan"))
+    L.conv_igemm(xg, wf, ysp, N=N, IH=H, IW=W, IC=IC, OH=OH, OW=OW, OC=OC, KH=k, KW=k, stride=s, dil=d, pad=pad, bm_hint=257)
+    np.testing.assert_allclose(ysp.float().cpu().numpy(), _nhwc(y.detach()).numpy(), **tol)
     if IC % 256 == 0:                     # dgrad: the conv's IC is the GEMM's N
         dxg = torch.empty(N, H, W, IC, device=dev, dtype=tdt)
         L.conv_igemm(_nhwc(dy).to(dev, tdt), wt, dxg, N=N, IH=OH, IW=OW, IC=OC, OH=H, OW=W, OC=IC, KH=k, KW=k, stride=s, dil=d,

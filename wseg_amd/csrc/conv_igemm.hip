@@ -11,6 +11,7 @@
 // LDS rows are XOR-swizzled at 16-B granularity (phys = chunk ^ ((row>>1)&7)) — applied on the
 // DMA source side and on the ds_read side (the LDS image itself stays lane-linear).
 #include <stdlib.h>
+#include <algorithm>
 #include "common.h"
 
 namespace {
@@ -548,21 +549,39 @@ extern "C" int wseg_conv_igemm(const wseg_conv_desc* d, void* stream) {
   a.row0 = 0;
   // 256x256 phase-pipelined tiles (bf16, OC >= 256): chosen when the (1 workgroup / CU) rounds are full enough
   bool big = false;
-  if (d->dtype == WSEG_BF16 && d->OC % 256 == 0 && d->bm_hint != 64 && d->bm_hint != 128 && d->bm_hint >= 0) {
+  if (d->dtype == WSEG_BF16 && d->OC % 256 == 0 && d->bm_hint != 64 && d->bm_hint != 128 && d->bm_hint >= 0) {   // (257: test hook, forces the row split)
     const long t256 = ((M + 255) / 256) * ((d->OC + 255) / 256);
     const long rounds = (t256 + 255) / 256;
     static const int auto256 = getenv("WSEG_CONV256") ? atoi(getenv("WSEG_CONV256")) : 1;   // (0: A/B switch)
-    big = d->bm_hint == 256 || (auto256 && t256 >= 200 && (double)t256 / (double)(rounds * 256) >= 0.80);
+    static const int split_tail = getenv("WSEG_CONV_SPLIT") ? atoi(getenv("WSEG_CONV_SPLIT")) : 0;
+    big = d->bm_hint == 256 || d->bm_hint == 257 ||
+          (auto256 && ((t256 >= 200 && (double)t256 / (double)(rounds * 256) >= 0.80) || (split_tail && d->bm_hint == 0 && t256 >= 256)));
     if (big)
       WSEG_CHECK(d->IH <= 16384 && d->IW <= 16384 && d->OH <= 16384 && d->OW <= 16384 && d->pad <= 4096 &&
                  (long)d->N * d->IH * d->IW + (long)d->N * d->IH2 * d->IW2 < (1L << 31), "conv_igemm: shape too large for the 256-tile kernel");
   }
   if (big) {
+    const int ntn128 = a.ntn;
     a.ntn = (d->OC + 255) / 256;
-    a.nwg = (int)(((M + 255) / 256) * a.ntn);
+    const long ntm = (M + 255) / 256;
+    long main_tm = ntm;                              // row tiles given to the 256-tile kernel
+    // WSEG_CONV_SPLIT=1 (experiment, off): only the FULL rounds go to the 256-tile kernel and the remaining rows to the
+    // 128-tile kernel (quarter-size tiles, a shorter tail).  Measured: no gain (26.35 vs 26.55 ms/step of conv time,
+    // layers move +-8 % either way) — a partly filled last round runs faster per tile, rounds are not discrete here either.
+    static const int split_tail = getenv("WSEG_CONV_SPLIT") ? atoi(getenv("WSEG_CONV_SPLIT")) : 0;
+    const long t256 = ntm * a.ntn, full = t256 / 256, rem = t256 % 256;
+    if ((split_tail && d->bm_hint == 0 && full >= 1 && rem > 0 && rem <= 208 && 256 % a.ntn == 0) || d->bm_hint == 257)
+      main_tm = d->bm_hint == 257 ? std::max(1L, ntm / 2) : full * 256 / a.ntn;
+    a.nwg = (int)(main_tm * a.ntn);
     if (d->epi == 0) hipLaunchKernelGGL(conv_igemm256_kernel<0>, dim3(a.nwg), dim3(512), 0, s, a);
     else if (d->epi == 1) hipLaunchKernelGGL(conv_igemm256_kernel<1>, dim3(a.nwg), dim3(512), 0, s, a);
     else hipLaunchKernelGGL(conv_igemm256_kernel<2>, dim3(a.nwg), dim3(512), 0, s, a);
+    if (main_tm < ntm) {
+      a.row0 = (int)(main_tm * 256);
+      a.ntn = ntn128;
+      a.nwg = (int)(((M - a.row0 + 127) / 128) * a.ntn);
+      WSEG_LAUNCH_CONV(128);
+    }
   } else if (small) {
     a.nwg = (int)(((M + 63) / 64) * a.ntn);
     WSEG_LAUNCH_CONV(64);
