@@ -20,6 +20,8 @@ SHAPES = [  # name, H (view 1; view 2 = H*128/448), IC, OC, k, stride, dil
     ("G18 2048->1024 1x1", 56, 2048, 1024, 1, 1, 1),
     ("G11 512->1024 1x1", 56, 512, 1024, 1, 1, 1),
     ("G9 256->512 3x3 s2", 112, 256, 512, 3, 2, 1),
+    ("G4 128->128 3x3 224^2", 224, 128, 128, 3, 1, 1),
+    ("G3 64->128 3x3 s2 448^2", 448, 64, 128, 3, 2, 1),
 ]
 
 
@@ -38,7 +40,10 @@ def main():
     tdt = torch.bfloat16 if which == "bf16" else torch.float32
     dev = "cuda"
     N = 16
+    only = [a_[7:] for a_ in sys.argv if a_.startswith("--only=")]
     for name, H, IC, OC, k, s, d in SHAPES:
+        if only and not any(o in name for o in only):
+            continue
         pad = d * (k // 2)
         osz = lambda h: (h + 2 * pad - d * (k - 1) - 1) // s + 1
         H2 = H * 128 // 448

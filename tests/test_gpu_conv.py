@@ -81,7 +81,7 @@ def test_conv_fwd_dgrad_wgrad(case, dt, bm):
     assert np.abs(dwg.cpu().numpy() - 2 * ref).max() / scale < 2 * wtol
 
 
-@pytest.mark.parametrize("dt,OC,bm", [("f32", 128, 0), ("bf16", 128, 0), ("bf16", 256, 256)])
+@pytest.mark.parametrize("dt,OC,bm", [("f32", 128, 0), ("bf16", 128, 0), ("bf16", 256, 256), ("bf16", 128, 258)])
 def test_conv_epilogues(dt, OC, bm):
     """fused BN-ReLU-dropout second output (forward) and masked-scale (+residual) epilogue (backward);
     bm=256: the 256x256 phase-pipelined kernel (300 rows = one full + one partial row tile)."""
@@ -245,6 +245,10 @@ def test_conv256_fwd_dgrad(case):
     ysp = torch.full_like(yg, float("nan"))
     L.conv_igemm(xg, wf, ysp, N=N, IH=H, IW=W, IC=IC, OH=OH, OW=OW, OC=OC, KH=k, KW=k, stride=s, dil=d, pad=pad, bm_hint=257)
     np.testing.assert_allclose(ysp.float().cpu().numpy(), _nhwc(y.detach()).numpy(), **tol)
+    # the 256 x 128 tile kernel (OC % 128 == 0)
+    y2n = torch.full_like(yg, float("nan"))
+    L.conv_igemm(xg, wf, y2n, N=N, IH=H, IW=W, IC=IC, OH=OH, OW=OW, OC=OC, KH=k, KW=k, stride=s, dil=d, pad=pad, bm_hint=258)
+    np.testing.assert_allclose(y2n.float().cpu().numpy(), _nhwc(y.detach()).numpy(), **tol)
     if IC % 256 == 0:                     # dgrad: the conv's IC is the GEMM's N
         dxg = torch.empty(N, H, W, IC, device=dev, dtype=tdt)
         L.conv_igemm(_nhwc(dy).to(dev, tdt), wt, dxg, N=N, IH=OH, IW=OW, IC=OC, OH=H, OW=W, OC=IC, KH=k, KW=k, stride=s, dil=d,

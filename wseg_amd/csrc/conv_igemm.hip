@@ -506,6 +506,174 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const Args a) {
   }
 }
 
+
+// ---- 256(M) x 128(N) bf16 phase-pipelined variant: layers with OC = 128 (the frozen 224x224 prefix) and narrow tails.
+// 8 waves as 4(M) x 2(N), wave tile 64 x 64 = 4 x 4 accumulators; LDS = 2 K-tiles x {A0, A1, B} slots of
+// [128 rows][128 B] = 16 KiB each (96 KiB).  A K-tile is 2 phases of 16 MFMAs (32 rows x 64 cols of the wave tile each;
+// the B fragments of phase A are kept in registers for phase B):
+//     pA(u): A0(u+1), A1(u+1)      pB(u): B(u+2), counted s_waitcnt vmcnt(2)
+// 85 FLOP per filled byte (the 128^2 kernel: 64) and one barrier per 16 MFMAs, as in the 256^2 kernel.
+constexpr int TILE2N = 3 * HALF256, EPI_LD2N = 128 + 4;
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void conv_igemm256x128_kernel(const Args a) {
+  constexpr int DT = WSEG_BF16, ES = 2, CH = 8;
+  __shared__ __attribute__((aligned(16))) char smem[2 * TILE2N];
+  const wseg_conv_desc& d = a.d;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tile = xcd_remap(blockIdx.x, a.nwg);
+  const int tm = tile / a.ntn, tn = tile - tm * a.ntn;
+  const int m0 = a.row0 + tm * 256, n0 = tn * 128;
+  const int wr = wid >> 1, wc = wid & 1;
+  const int frow = lane & 15, fk = lane >> 4, sw = (lane >> 1) & 7;
+
+  const char* zero = reinterpret_cast<const char*>(g_wseg_zero_page);
+  const char* IN = reinterpret_cast<const char*>(d.in);
+  const char* Wp = reinterpret_cast<const char*>(d.w);
+
+  // staging: thread -> rows r0 + 64*j (j = 0..3) of the A tile, rows r0, r0 + 64 of the B tile (see the 256^2 kernel)
+  const int r0 = tid >> 3, pch = tid & 7;
+  const int lc = pch ^ ((r0 >> 1) & 7);
+  const char* zsrc = zero + pch * 16;
+  const char* INl = IN + lc * 16;
+  int a_base[4], a_yx[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int m = m0 + r0 + 64 * j;
+    if (m < a.M) {
+      const wseg_rowgeo rg = wseg_decode_row(d, m);
+      int iy0, ix0;
+      if (d.mode == 0) { iy0 = rg.oy * d.stride - d.pad; ix0 = rg.ox * d.stride - d.pad; }
+      else             { iy0 = rg.oy + d.pad;            ix0 = rg.ox + d.pad; }
+      a_base[j] = (int)rg.in_base;
+      a_yx[j] = (rg.n_glob >= d.N ? (int)0x80000000 : 0) | ((iy0 + 0x2000) << 16) | (ix0 + 0x2000);
+    } else {
+      a_base[j] = -1; a_yx[j] = (0x2000 << 16) | 0x2000;
+    }
+  }
+  const char* aptr[4];
+  unsigned a_live = 0;
+  const char* bptr = Wp + ((size_t)(n0 + r0) * a.taps * d.IC + (size_t)lc * CH) * ES;   // OC % 128 == 0 (host-checked)
+  const int brs = 64 * a.taps * d.IC * ES;
+  auto set_tap = [&](int tap) {
+    const int ky = tap / d.KW, kx = tap - ky * d.KW;
+    a_live = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int iy0 = ((a_yx[j] >> 16) & 0x7FFF) - 0x2000, ix0 = (a_yx[j] & 0xFFFF) - 0x2000;
+      const bool s2 = a_yx[j] < 0;
+      const int H = s2 ? d.IH2 : d.IH, W = s2 ? d.IW2 : d.IW;
+      int iy, ix; bool ok = a_base[j] >= 0;
+      if (d.mode == 0) {
+        iy = iy0 + ky * d.dil; ix = ix0 + kx * d.dil;
+      } else {
+        const int ty = iy0 - ky * d.dil, tx = ix0 - kx * d.dil;
+        ok = ok && ty >= 0 && tx >= 0;
+        if (d.stride == 1) { iy = ty; ix = tx; }
+        else { iy = ty / d.stride; ix = tx / d.stride; ok = ok && (iy * d.stride == ty) && (ix * d.stride == tx); }
+      }
+      ok = ok && iy >= 0 && iy < H && ix >= 0 && ix < W;
+      if (ok) { aptr[j] = INl + (size_t)(a_base[j] + iy * W + ix) * d.ld_in * ES; a_live |= 1u << j; }
+      else    { aptr[j] = zsrc; }
+    }
+  };
+  int a_tap = 0, a_cc = 0;
+  auto issue_a = [&](int buf) {                    // both halves of the NEXT A tile (4 pieces), then advance
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      char* dst = smem + buf * TILE2N + h * HALF256 + wid * 1024;
+      glds16(aptr[2 * h], dst);
+      glds16(aptr[2 * h + 1], dst + 8192);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) aptr[j] += ((a_live >> j) & 1u) << 7;
+    if (++a_cc == a.cpt) { a_cc = 0; if (++a_tap < a.taps) set_tap(a_tap); }
+  };
+  auto issue_b = [&](int buf) {                    // the NEXT B tile (2 pieces), then advance
+    char* dst = smem + buf * TILE2N + 2 * HALF256 + wid * 1024;
+    glds16(bptr, dst);
+    glds16(bptr + brs, dst + 8192);
+    bptr += 128;
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nt = a.taps * a.cpt;
+  set_tap(0);
+  issue_a(0); issue_b(0);
+  if (nt > 1) { issue_b(1); asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  bf16x8 af[2][2], bf[2][4];
+  auto ldA = [&](const char* aH, int ha) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        af[ks][i] = *reinterpret_cast<const bf16x8*>(aH + ((wr & 1) * 64 + ha * 32 + i * 16 + frow) * 128 + (((ks * 4 + fk) ^ sw) << 4));
+  };
+#define MFMA_H(HA)                                                                                           \
+  do {                                                                                                       \
+    __builtin_amdgcn_s_setprio(1);                                                                           \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                         \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                          \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                        \
+          acc[(HA) * 2 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][i], bf[ks][j], acc[(HA) * 2 + i][j], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                           \
+  } while (0)
+
+  for (int u = 0; u < nt; ++u) {
+    const int b = u & 1;
+    const char* aH = smem + b * TILE2N + (wr >> 1) * HALF256;
+    const char* bH = smem + b * TILE2N + 2 * HALF256;
+    // ---- pA: rows 0-31 of the wave tile
+    ldA(aH, 0);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        bf[ks][j] = *reinterpret_cast<const bf16x8*>(bH + (wc * 64 + j * 16 + frow) * 128 + (((ks * 4 + fk) ^ sw) << 4));
+    if (u + 1 < nt) issue_a(b ^ 1);
+    MFMA_H(0);
+    __builtin_amdgcn_s_barrier();
+    // ---- pB: rows 32-63; the counted wait publishes tile u+1 (only B(u+2) may stay in flight)
+    ldA(aH, 1);
+    if (u + 2 < nt) { issue_b(b); asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MFMA_H(1);
+    __builtin_amdgcn_s_barrier();
+  }
+#undef MFMA_H
+
+  // ---- epilogue: 2 passes of 128 rows
+  float* img = reinterpret_cast<float*>(smem);
+  float sc[8], sh[8];
+  epilogue_coeffs(d, n0, (tid & 15) * 8, sc, sh);
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) {
+    if ((wr >> 1) == ps) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int row = (wr & 1) * 64 + i * 16 + fk * 4;
+          const int col = wc * 64 + j * 16 + frow;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) img[(row + e) * EPI_LD2N + col] = acc[i][j][e];
+        }
+    }
+    __syncthreads();
+    epilogue_image<DT, EPI, 128, 128, EPI_LD2N, 512>(d, a.M, img, m0 + ps * 128, n0, tid, sc, sh);
+    __syncthreads();
+  }
+}
+
 }  // namespace
 
 extern "C" int wseg_conv_igemm(const wseg_conv_desc* d, void* stream) {
@@ -549,7 +717,7 @@ extern "C" int wseg_conv_igemm(const wseg_conv_desc* d, void* stream) {
   a.row0 = 0;
   // 256x256 phase-pipelined tiles (bf16, OC >= 256): chosen when the (1 workgroup / CU) rounds are full enough
   bool big = false;
-  if (d->dtype == WSEG_BF16 && d->OC % 256 == 0 && d->bm_hint != 64 && d->bm_hint != 128 && d->bm_hint >= 0) {   // (257: test hook, forces the row split)
+  if (d->dtype == WSEG_BF16 && d->OC % 256 == 0 && d->bm_hint != 64 && d->bm_hint != 128 && d->bm_hint != 258 && d->bm_hint >= 0) {   // (257: test hook, forces the row split)
     const long t256 = ((M + 255) / 256) * ((d->OC + 255) / 256);
     const long rounds = (t256 + 255) / 256;
     static const int auto256 = getenv("WSEG_CONV256") ? atoi(getenv("WSEG_CONV256")) : 1;   // (0: A/B switch)
@@ -560,7 +728,19 @@ extern "C" int wseg_conv_igemm(const wseg_conv_desc* d, void* stream) {
       WSEG_CHECK(d->IH <= 16384 && d->IW <= 16384 && d->OH <= 16384 && d->OW <= 16384 && d->pad <= 4096 &&
                  (long)d->N * d->IH * d->IW + (long)d->N * d->IH2 * d->IW2 < (1L << 31), "conv_igemm: shape too large for the 256-tile kernel");
   }
-  if (big) {
+  // 256 x 128 phase-pipelined tiles: OC = 128 layers with many pixels (the frozen 224x224 prefix); 258 forces it
+  static const int auto2n = getenv("WSEG_CONV256X128") ? atoi(getenv("WSEG_CONV256X128")) : 1;
+  const bool mid = !big && d->dtype == WSEG_BF16 && d->OC % 128 == 0 &&
+                   (d->bm_hint == 258 || (auto2n && d->bm_hint == 0 && d->OC == 128 && (M + 255) / 256 >= 512));
+  if (mid) {
+    WSEG_CHECK(d->IH <= 16384 && d->IW <= 16384 && d->OH <= 16384 && d->OW <= 16384 && d->pad <= 4096 &&
+               (long)d->N * d->IH * d->IW + (long)d->N * d->IH2 * d->IW2 < (1L << 31), "conv_igemm: shape too large for the 256x128-tile kernel");
+    a.ntn = d->OC / 128;
+    a.nwg = (int)(((M + 255) / 256) * a.ntn);
+    if (d->epi == 0) hipLaunchKernelGGL(conv_igemm256x128_kernel<0>, dim3(a.nwg), dim3(512), 0, s, a);
+    else if (d->epi == 1) hipLaunchKernelGGL(conv_igemm256x128_kernel<1>, dim3(a.nwg), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL(conv_igemm256x128_kernel<2>, dim3(a.nwg), dim3(512), 0, s, a);
+  } else if (big) {
     const int ntn128 = a.ntn;
     a.ntn = (d->OC + 255) / 256;
     const long ntm = (M + 255) / 256;
