@@ -728,8 +728,10 @@ extern "C" int wseg_conv_igemm(const wseg_conv_desc* d, void* stream) {
       WSEG_CHECK(d->IH <= 16384 && d->IW <= 16384 && d->OH <= 16384 && d->OW <= 16384 && d->pad <= 4096 &&
                  (long)d->N * d->IH * d->IW + (long)d->N * d->IH2 * d->IW2 < (1L << 31), "conv_igemm: shape too large for the 256-tile kernel");
   }
-  // 256 x 128 phase-pipelined tiles: OC = 128 layers with many pixels (the frozen 224x224 prefix); 258 forces it
-  static const int auto2n = getenv("WSEG_CONV256X128") ? atoi(getenv("WSEG_CONV256X128")) : 1;
+  // 256 x 128 phase-pipelined tiles (bm_hint 258, or WSEG_CONV256X128=1 for OC = 128 layers with many pixels).  Measured on
+  // the frozen 224x224 prefix (128->128 3x3, K = 1152): 703 vs 700 TF/s for the 128^2 kernel — those layers are bound by
+  // their epilogue (18 K-tiles per tile), which two resident workgroups per CU overlap and one cannot; off by default.
+  static const int auto2n = getenv("WSEG_CONV256X128") ? atoi(getenv("WSEG_CONV256X128")) : 0;
   const bool mid = !big && d->dtype == WSEG_BF16 && d->OC % 128 == 0 &&
                    (d->bm_hint == 258 || (auto2n && d->bm_hint == 0 && d->OC == 128 && (M + 255) / 256 >= 512));
   if (mid) {
