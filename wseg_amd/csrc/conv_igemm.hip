@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const Args a) {
 // Epilogue: 4 passes of 64 rows through a 65-KiB f32 LDS image, same fused epilogue as the 128^2 kernel.
 constexpr int HALF256 = 16384, TILE256 = 4 * HALF256, EPI_LD256 = 256 + 4;
 
-template <int EPI>
+template <int EPI, int STG>
 __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const Args a) {
   constexpr int DT = WSEG_BF16, ES = 2, CH = 8;
   __shared__ __attribute__((aligned(16))) char smem[2 * TILE256];
@@ -454,30 +454,67 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const Args a) {
     __builtin_amdgcn_s_setprio(0);                                                                           \
   } while (0)
 
-  for (int u = 0; u < nt; ++u) {
-    const int b = u & 1;
-    const char* aH = smem + b * TILE256 + wr * HALF256;
-    const char* bH = smem + b * TILE256 + (2 + (wc >> 1)) * HALF256;
-    // ---- p1: quadrant (0,0)
-    ldA(aH, 0); ldB(bH, 0, b0);
-    if (u + 1 < nt) issue_a(0, b ^ 1);
-    MFMA_Q(0, 0, b0);
-    __builtin_amdgcn_s_barrier();
-    // ---- p2: quadrant (0,1)
-    ldB(bH, 1, b1);
-    if (u + 1 < nt) { issue_a(1, b ^ 1); advance_a(); }
-    MFMA_Q(0, 1, b1);
-    __builtin_amdgcn_s_barrier();
-    // ---- p3: quadrant (1,1)
-    ldA(aH, 1);
-    if (u + 2 < nt) issue_b(0, b);
-    MFMA_Q(1, 1, b1);
-    __builtin_amdgcn_s_barrier();
-    // ---- p4: quadrant (1,0); the counted wait publishes tile u+1 (only B0/B1(u+2) may stay in flight)
-    if (u + 2 < nt) { issue_b(1, b); advance_b(); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    MFMA_Q(1, 0, b0);
-    __builtin_amdgcn_s_barrier();
+  if constexpr (STG == 0) {
+    for (int u = 0; u < nt; ++u) {
+      const int b = u & 1;
+      const char* aH = smem + b * TILE256 + wr * HALF256;
+      const char* bH = smem + b * TILE256 + (2 + (wc >> 1)) * HALF256;
+      // ---- p1: quadrant (0,0)
+      ldA(aH, 0); ldB(bH, 0, b0);
+      if (u + 1 < nt) issue_a(0, b ^ 1);
+      MFMA_Q(0, 0, b0);
+      __builtin_amdgcn_s_barrier();
+      // ---- p2: quadrant (0,1)
+      ldB(bH, 1, b1);
+      if (u + 1 < nt) { issue_a(1, b ^ 1); advance_a(); }
+      MFMA_Q(0, 1, b1);
+      __builtin_amdgcn_s_barrier();
+      // ---- p3: quadrant (1,1)
+      ldA(aH, 1);
+      if (u + 2 < nt) issue_b(0, b);
+      MFMA_Q(1, 1, b1);
+      __builtin_amdgcn_s_barrier();
+      // ---- p4: quadrant (1,0); the counted wait publishes tile u+1 (only B0/B1(u+2) may stay in flight)
+      if (u + 2 < nt) { issue_b(1, b); advance_b(); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      MFMA_Q(1, 0, b0);
+      __builtin_amdgcn_s_barrier();
+    }
+  } else {
+    // Ping-pong schedule: the two waves of every SIMD (wave w and w+4 = the two M halves, wr = 0 / 1) run HALF A PHASE
+    // apart.  Every phase is split into a read slot (fragment ds_reads, LDS-DMA issue, address work) and an MFMA slot
+    // (16 MFMAs) with a barrier after each; waves 4-7 start one slot late, so while one wave of a SIMD feeds the matrix
+    // pipe the other one does its reads — the LDS latency and the VALU work that the lock-step schedule exposes before
+    // every MFMA burst are hidden.  Slot refills are unchanged (A(u+1) in R1/R2, B(u+2) in R3/R4): a slot's last reader
+    // is the late group's read slot, one barrier before the early group's next issue into it.  Every wave executes
+    // 8 barriers per K-tile plus ONE extra (late group: before the loop, early group: after it), so the counts match.
+    if (wr == 1) __builtin_amdgcn_s_barrier();
+    for (int u = 0; u < nt; ++u) {
+      const int b = u & 1;
+      const char* aH = smem + b * TILE256 + wr * HALF256;
+      const char* bH = smem + b * TILE256 + (2 + (wc >> 1)) * HALF256;
+      ldA(aH, 0); ldB(bH, 0, b0);
+      if (u + 1 < nt) issue_a(0, b ^ 1);
+      __builtin_amdgcn_s_barrier();
+      MFMA_Q(0, 0, b0);
+      __builtin_amdgcn_s_barrier();
+      ldB(bH, 1, b1);
+      if (u + 1 < nt) { issue_a(1, b ^ 1); advance_a(); }
+      __builtin_amdgcn_s_barrier();
+      MFMA_Q(0, 1, b1);
+      __builtin_amdgcn_s_barrier();
+      ldA(aH, 1);
+      if (u + 2 < nt) issue_b(0, b);
+      __builtin_amdgcn_s_barrier();
+      MFMA_Q(1, 1, b1);
+      __builtin_amdgcn_s_barrier();
+      if (u + 2 < nt) { issue_b(1, b); advance_b(); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      MFMA_Q(1, 0, b0);
+      __builtin_amdgcn_s_barrier();
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();
   }
 #undef MFMA_Q
 
@@ -755,9 +792,16 @@ extern "C" int wseg_conv_igemm(const wseg_conv_desc* d, void* stream) {
     if ((split_tail && d->bm_hint == 0 && full >= 1 && rem > 0 && rem <= 208 && 256 % a.ntn == 0) || d->bm_hint == 257)
       main_tm = d->bm_hint == 257 ? std::max(1L, ntm / 2) : full * 256 / a.ntn;
     a.nwg = (int)(main_tm * a.ntn);
-    if (d->epi == 0) hipLaunchKernelGGL(conv_igemm256_kernel<0>, dim3(a.nwg), dim3(512), 0, s, a);
-    else if (d->epi == 1) hipLaunchKernelGGL(conv_igemm256_kernel<1>, dim3(a.nwg), dim3(512), 0, s, a);
-    else hipLaunchKernelGGL(conv_igemm256_kernel<2>, dim3(a.nwg), dim3(512), 0, s, a);
+    static const int stagger = getenv("WSEG_CONV_STAGGER") ? atoi(getenv("WSEG_CONV_STAGGER")) : 1;   // ping-pong schedule (0: lock-step, A/B)
+    if (stagger) {
+      if (d->epi == 0) hipLaunchKernelGGL((conv_igemm256_kernel<0, 1>), dim3(a.nwg), dim3(512), 0, s, a);
+      else if (d->epi == 1) hipLaunchKernelGGL((conv_igemm256_kernel<1, 1>), dim3(a.nwg), dim3(512), 0, s, a);
+      else hipLaunchKernelGGL((conv_igemm256_kernel<2, 1>), dim3(a.nwg), dim3(512), 0, s, a);
+    } else {
+      if (d->epi == 0) hipLaunchKernelGGL((conv_igemm256_kernel<0, 0>), dim3(a.nwg), dim3(512), 0, s, a);
+      else if (d->epi == 1) hipLaunchKernelGGL((conv_igemm256_kernel<1, 0>), dim3(a.nwg), dim3(512), 0, s, a);
+      else hipLaunchKernelGGL((conv_igemm256_kernel<2, 0>), dim3(a.nwg), dim3(512), 0, s, a);
+    }
     if (main_tm < ntm) {
       a.row0 = (int)(main_tm * 256);
       a.ntn = ntn128;

@@ -26,6 +26,9 @@ struct Args {
   int M, taps, nto, nti, ntiles;
   int pix_per_split;
   int nsplit, nwg;
+  int stagger;       // 1 = ping-pong schedule of the pipe kernel (WSEG_WGRAD_STAGGER; off: its read slots — 24/8/16/0 transposed
+                     //     reads + pixel addressing — are longer and less even than an MFMA slot, the stagger then costs time)
+  int diag;          // 0 = normal; timing diagnostics (WSEG_WGRAD_DIAG): 1 = no epilogue stores, 2 = plain stores
 };
 
 template <int DT, int BO, int BI, int WR, int WC>
@@ -410,6 +413,10 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pipe_kernel(const Args a) {
     __builtin_amdgcn_s_setprio(0);                                                                              \
   } while (0)
 
+  // Ping-pong schedule (see conv_igemm256_kernel): waves 4-7 (wr = 1, the second wave of every SIMD) run one slot
+  // behind waves 0-3; every phase = a read slot (transposed fragment reads + LDS-DMA issue + address work) and an MFMA
+  // slot, one barrier after each, so one wave of a SIMD reads while the other feeds the matrix pipe.
+  if (a.stagger && wr == 1) asm volatile("s_barrier" ::: "memory");
   for (int u = 0; u < nt; ++u) {
     const int b = u & 1;
     const unsigned abase = lds0 + b * TILE + wr * HALF;
@@ -417,6 +424,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pipe_kernel(const Args a) {
     // ---- p1: quadrant (0,0)
     LOAD_A(0) LOAD_B(0, vb0)
     if (u + 1 < nt) issue_y(0, b ^ 1);
+    if (a.stagger) asm volatile("s_barrier" ::: "memory");
     WAIT_LDS();
     PACK_A() PACK_B(b0, vb0)
     MFMA_Q(0, 0, b0);
@@ -424,6 +432,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pipe_kernel(const Args a) {
     // ---- p2: quadrant (0,1)
     LOAD_B(1, vb1)
     if (u + 1 < nt) issue_y(1, b ^ 1);
+    if (a.stagger) asm volatile("s_barrier" ::: "memory");
     WAIT_LDS();
     PACK_B(b1, vb1)
     MFMA_Q(0, 1, b1);
@@ -431,6 +440,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pipe_kernel(const Args a) {
     // ---- p3: quadrant (1,1)
     LOAD_A(1)
     if (u + 2 < nt) { x_prepare(); issue_x(0, b); }
+    if (a.stagger) asm volatile("s_barrier" ::: "memory");
     WAIT_LDS();
     PACK_A()
     MFMA_Q(1, 1, b1);
@@ -438,9 +448,11 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pipe_kernel(const Args a) {
     // ---- p4: quadrant (1,0); counted wait: only X0/X1(u+2) may stay in flight
     if (u + 2 < nt) { issue_x(1, b); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (a.stagger) asm volatile("s_barrier" ::: "memory");
     MFMA_Q(1, 0, b0);
     asm volatile("s_barrier" ::: "memory");
   }
+  if (a.stagger && wr == 0) asm volatile("s_barrier" ::: "memory");
 #undef TR
 #undef LOAD_A
 #undef LOAD_B
@@ -472,8 +484,11 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pipe_kernel(const Args a) {
     for (int idx = tid; idx < EPI_ROWS * BI; idx += NT) {
       const int row = idx / BI, col = idx - row * BI;
       const int oc = oc0 + ps * EPI_ROWS + row, ic = ic0 + col;
-      if (oc < d.OC_dw && ic < d.IC_dw)
-        atomicAdd(&d.dw[(size_t)oc * row_stride + (size_t)tap * d.IC_dw + ic], img[row * EPI_LD + col]);
+      if (oc < d.OC_dw && ic < d.IC_dw) {
+        float* dst = &d.dw[(size_t)oc * row_stride + (size_t)tap * d.IC_dw + ic];
+        if (a.diag == 0) atomicAdd(dst, img[row * EPI_LD + col]);
+        else if (a.diag == 2) *dst = img[row * EPI_LD + col];       // (timing diagnostics only: plain store / nothing)
+      }
     }
     __syncthreads();
   }
@@ -527,6 +542,10 @@ extern "C" int wseg_conv_wgrad(const wseg_wgrad_desc* d, void* stream) {
   split = (int)((M + pps - 1) / pps);
   a.nsplit = split;
   a.nwg = a.ntiles * split;
+  static const int diag = getenv("WSEG_WGRAD_DIAG") ? atoi(getenv("WSEG_WGRAD_DIAG")) : 0;
+  a.diag = diag;
+  static const int stagger = getenv("WSEG_WGRAD_STAGGER") ? atoi(getenv("WSEG_WGRAD_STAGGER")) : 0;   // measured: 17.1 vs 14.8 ms/step (slower)
+  a.stagger = stagger;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(a.nwg);
   static const bool use_pipe = !(getenv("WSEG_WGRAD_PIPE") && getenv("WSEG_WGRAD_PIPE")[0] == '0');
