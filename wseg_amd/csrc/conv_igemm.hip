@@ -480,7 +480,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const Args a) {
       MFMA_Q(1, 0, b0);
       __builtin_amdgcn_s_barrier();
     }
-  } else {
+  } else if constexpr (STG == 1) {
     // Ping-pong schedule: the two waves of every SIMD (wave w and w+4 = the two M halves, wr = 0 / 1) run HALF A PHASE
     // apart.  Every phase is split into a read slot (fragment ds_reads, LDS-DMA issue, address work) and an MFMA slot
     // (16 MFMAs) with a barrier after each; waves 4-7 start one slot late, so while one wave of a SIMD feeds the matrix
@@ -515,6 +515,30 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const Args a) {
       __builtin_amdgcn_s_barrier();
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();
+  } else {
+    // STG 2 / 3: TWO phases of 32 MFMAs per K-tile (rows 0-63 then 64-127 of the wave tile, both B fragments read in
+    // phase 1 and kept): half the barriers.  2 = ping-pong (waves 4-7 one slot behind), 3 = lock-step.
+    constexpr bool stg = STG == 2;
+    if (stg && wr == 1) __builtin_amdgcn_s_barrier();
+    for (int u = 0; u < nt; ++u) {
+      const int b = u & 1;
+      const char* aH = smem + b * TILE256 + wr * HALF256;
+      const char* bH = smem + b * TILE256 + (2 + (wc >> 1)) * HALF256;
+      ldA(aH, 0); ldB(bH, 0, b0); ldB(bH, 1, b1);
+      if (u + 1 < nt) { issue_a(0, b ^ 1); issue_a(1, b ^ 1); advance_a(); }
+      if (stg) __builtin_amdgcn_s_barrier();
+      MFMA_Q(0, 0, b0);
+      MFMA_Q(0, 1, b1);
+      __builtin_amdgcn_s_barrier();
+      ldA(aH, 1);
+      if (u + 2 < nt) { issue_b(0, b); issue_b(1, b); advance_b(); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (stg) __builtin_amdgcn_s_barrier();
+      MFMA_Q(1, 1, b1);
+      MFMA_Q(1, 0, b0);
+      __builtin_amdgcn_s_barrier();
+    }
+    if (stg && wr == 0) __builtin_amdgcn_s_barrier();
   }
 #undef MFMA_Q
 
@@ -792,12 +816,17 @@ extern "C" int wseg_conv_igemm(const wseg_conv_desc* d, void* stream) {
     if ((split_tail && d->bm_hint == 0 && full >= 1 && rem > 0 && rem <= 208 && 256 % a.ntn == 0) || d->bm_hint == 257)
       main_tm = d->bm_hint == 257 ? std::max(1L, ntm / 2) : full * 256 / a.ntn;
     a.nwg = (int)(main_tm * a.ntn);
-    static const int stagger = getenv("WSEG_CONV_STAGGER") ? atoi(getenv("WSEG_CONV_STAGGER")) : 1;   // ping-pong schedule (0: lock-step, A/B)
-    if (stagger) {
-      if (d->epi == 0) hipLaunchKernelGGL((conv_igemm256_kernel<0, 1>), dim3(a.nwg), dim3(512), 0, s, a);
-      else if (d->epi == 1) hipLaunchKernelGGL((conv_igemm256_kernel<1, 1>), dim3(a.nwg), dim3(512), 0, s, a);
-      else hipLaunchKernelGGL((conv_igemm256_kernel<2, 1>), dim3(a.nwg), dim3(512), 0, s, a);
-    } else {
+    static const int stagger = getenv("WSEG_CONV_STAGGER") ? atoi(getenv("WSEG_CONV_STAGGER")) : 2;   // 0: 4 phases lock-step, 1: 4 phases ping-pong, 2: 2 phases ping-pong (best), 3: 2 phases lock-step
+#define WSEG_LAUNCH_256(STG_)                                                                                          \
+  do {                                                                                                                 \
+    if (d->epi == 0) hipLaunchKernelGGL((conv_igemm256_kernel<0, STG_>), dim3(a.nwg), dim3(512), 0, s, a);              \
+    else if (d->epi == 1) hipLaunchKernelGGL((conv_igemm256_kernel<1, STG_>), dim3(a.nwg), dim3(512), 0, s, a);         \
+    else hipLaunchKernelGGL((conv_igemm256_kernel<2, STG_>), dim3(a.nwg), dim3(512), 0, s, a);                          \
+  } while (0)
+    if (stagger == 1) WSEG_LAUNCH_256(1);
+    else if (stagger == 2) WSEG_LAUNCH_256(2);
+    else if (stagger == 3) WSEG_LAUNCH_256(3);
+    else {
       if (d->epi == 0) hipLaunchKernelGGL((conv_igemm256_kernel<0, 0>), dim3(a.nwg), dim3(512), 0, s, a);
       else if (d->epi == 1) hipLaunchKernelGGL((conv_igemm256_kernel<1, 0>), dim3(a.nwg), dim3(512), 0, s, a);
       else hipLaunchKernelGGL((conv_igemm256_kernel<2, 0>), dim3(a.nwg), dim3(512), 0, s, a);

@@ -255,6 +255,7 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void conv_wgrad_kernel(const Args 
 // and the only DMA wait is a counted s_waitcnt vmcnt(4) in p4.  One raw s_barrier per phase.  The transposed
 // fragment reads go through inline asm (hipcc would put vmcnt(0) in front of ds_read_tr builtins while
 // LDS-DMA is in flight), with an explicit lgkmcnt(0) + sched_barrier before the MFMAs.
+template <int SCHED>   // 0/1: 4 phases lock-step / ping-pong; 2/3: 2 phases lock-step / ping-pong
 __global__ __launch_bounds__(512, 2) void conv_wgrad_pipe_kernel(const Args a) {
   constexpr int BO = 256, BI = 256, NT = 512;
   constexpr int PK = 64, HALF = 16384, TILE = 4 * HALF, ROWB = 256;
@@ -413,10 +414,45 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pipe_kernel(const Args a) {
     __builtin_amdgcn_s_setprio(0);                                                                              \
   } while (0)
 
+  if constexpr (SCHED >= 2) {
+    // TWO phases of 32 MFMAs per K-tile (rows 0-63, then 64-127 of the wave tile; both B fragments are read in phase 1 and
+    // kept), each a read slot + an MFMA slot.  stagger == 3: waves 4-7 (the second wave of every SIMD) run one slot behind
+    // waves 0-3, so one wave of a SIMD does its 32 / 16 transposed reads, LDS-DMA issue and pixel addressing while the
+    // other feeds the matrix pipe for 512 cycles.  Refills: dY0/dY1(u+1) in R1, X0/X1(u+2) + the counted wait in R2 — a
+    // slot's last reader (the late group's read slot) is always one barrier before the early group's next issue into it.
+    constexpr bool stg = SCHED == 3;
+    if (stg && wr == 1) asm volatile("s_barrier" ::: "memory");
+    for (int u = 0; u < nt; ++u) {
+      const int b = u & 1;
+      const unsigned abase = lds0 + b * TILE + wr * HALF;
+      const unsigned bbase = lds0 + b * TILE + (2 + (wc >> 1)) * HALF;
+      // ---- R1 / M1: rows 0-63 x all 64 columns
+      LOAD_A(0) LOAD_B(0, vb0) LOAD_B(1, vb1)
+      if (u + 1 < nt) { issue_y(0, b ^ 1); issue_y(1, b ^ 1); }
+      if (stg) asm volatile("s_barrier" ::: "memory");
+      WAIT_LDS();
+      PACK_A() PACK_B(b0, vb0) PACK_B(b1, vb1)
+      MFMA_Q(0, 0, b0);
+      MFMA_Q(0, 1, b1);
+      asm volatile("s_barrier" ::: "memory");
+      // ---- R2 / M2: rows 64-127; the counted wait publishes tile u+1 (only X0/X1(u+2) may stay in flight)
+      LOAD_A(1)
+      if (u + 2 < nt) { x_prepare(); issue_x(0, b); issue_x(1, b); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (stg) asm volatile("s_barrier" ::: "memory");
+      WAIT_LDS();
+      PACK_A()
+      MFMA_Q(1, 1, b1);
+      MFMA_Q(1, 0, b0);
+      asm volatile("s_barrier" ::: "memory");
+    }
+    if (stg && wr == 0) asm volatile("s_barrier" ::: "memory");
+  } else {
   // Ping-pong schedule (see conv_igemm256_kernel): waves 4-7 (wr = 1, the second wave of every SIMD) run one slot
   // behind waves 0-3; every phase = a read slot (transposed fragment reads + LDS-DMA issue + address work) and an MFMA
   // slot, one barrier after each, so one wave of a SIMD reads while the other feeds the matrix pipe.
-  if (a.stagger && wr == 1) asm volatile("s_barrier" ::: "memory");
+  constexpr bool stg1 = SCHED == 1;
+  if (stg1 && wr == 1) asm volatile("s_barrier" ::: "memory");
   for (int u = 0; u < nt; ++u) {
     const int b = u & 1;
     const unsigned abase = lds0 + b * TILE + wr * HALF;
@@ -424,7 +460,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pipe_kernel(const Args a) {
     // ---- p1: quadrant (0,0)
     LOAD_A(0) LOAD_B(0, vb0)
     if (u + 1 < nt) issue_y(0, b ^ 1);
-    if (a.stagger) asm volatile("s_barrier" ::: "memory");
+    if (stg1) asm volatile("s_barrier" ::: "memory");
     WAIT_LDS();
     PACK_A() PACK_B(b0, vb0)
     MFMA_Q(0, 0, b0);
@@ -432,7 +468,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pipe_kernel(const Args a) {
     // ---- p2: quadrant (0,1)
     LOAD_B(1, vb1)
     if (u + 1 < nt) issue_y(1, b ^ 1);
-    if (a.stagger) asm volatile("s_barrier" ::: "memory");
+    if (stg1) asm volatile("s_barrier" ::: "memory");
     WAIT_LDS();
     PACK_B(b1, vb1)
     MFMA_Q(0, 1, b1);
@@ -440,7 +476,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pipe_kernel(const Args a) {
     // ---- p3: quadrant (1,1)
     LOAD_A(1)
     if (u + 2 < nt) { x_prepare(); issue_x(0, b); }
-    if (a.stagger) asm volatile("s_barrier" ::: "memory");
+    if (stg1) asm volatile("s_barrier" ::: "memory");
     WAIT_LDS();
     PACK_A()
     MFMA_Q(1, 1, b1);
@@ -448,11 +484,12 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pipe_kernel(const Args a) {
     // ---- p4: quadrant (1,0); counted wait: only X0/X1(u+2) may stay in flight
     if (u + 2 < nt) { issue_x(1, b); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (a.stagger) asm volatile("s_barrier" ::: "memory");
+    if (stg1) asm volatile("s_barrier" ::: "memory");
     MFMA_Q(1, 0, b0);
     asm volatile("s_barrier" ::: "memory");
   }
-  if (a.stagger && wr == 0) asm volatile("s_barrier" ::: "memory");
+  if (stg1 && wr == 0) asm volatile("s_barrier" ::: "memory");
+  }
 #undef TR
 #undef LOAD_A
 #undef LOAD_B
@@ -544,13 +581,17 @@ extern "C" int wseg_conv_wgrad(const wseg_wgrad_desc* d, void* stream) {
   a.nwg = a.ntiles * split;
   static const int diag = getenv("WSEG_WGRAD_DIAG") ? atoi(getenv("WSEG_WGRAD_DIAG")) : 0;
   a.diag = diag;
-  static const int stagger = getenv("WSEG_WGRAD_STAGGER") ? atoi(getenv("WSEG_WGRAD_STAGGER")) : 0;   // measured: 17.1 vs 14.8 ms/step (slower)
+  static const int stagger = getenv("WSEG_WGRAD_STAGGER") ? atoi(getenv("WSEG_WGRAD_STAGGER")) : 2;   // (2 measured best: 14.06 vs 14.85 / 15.9 ms/step) 0/1: 4 phases lock-step / ping-pong (1 measured slower: 17.1 vs 14.8 ms/step); 2/3: 2 phases lock-step / ping-pong
   a.stagger = stagger;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(a.nwg);
   static const bool use_pipe = !(getenv("WSEG_WGRAD_PIPE") && getenv("WSEG_WGRAD_PIPE")[0] == '0');
-  if (big && use_pipe)
-    hipLaunchKernelGGL(conv_wgrad_pipe_kernel, grid, dim3(512), 0, s, a);
+  if (big && use_pipe) {
+    if (stagger == 3) hipLaunchKernelGGL(conv_wgrad_pipe_kernel<3>, grid, dim3(512), 0, s, a);
+    else if (stagger == 2) hipLaunchKernelGGL(conv_wgrad_pipe_kernel<2>, grid, dim3(512), 0, s, a);
+    else if (stagger == 1) hipLaunchKernelGGL(conv_wgrad_pipe_kernel<1>, grid, dim3(512), 0, s, a);
+    else hipLaunchKernelGGL(conv_wgrad_pipe_kernel<0>, grid, dim3(512), 0, s, a);
+  }
   else if (big)
     hipLaunchKernelGGL((conv_wgrad_kernel<WSEG_BF16, 256, 256, 2, 4>), grid, dim3(512), 0, s, a);
   else if (d->dtype == WSEG_BF16)
