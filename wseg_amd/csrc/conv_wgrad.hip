@@ -26,6 +26,7 @@ struct Args {
   int M, taps, nto, nti, ntiles;
   int pix_per_split;
   int nsplit, nwg;
+  int simple_adv, q64_1, r64_1, q64_2, r64_2;   // pipe kernel: 64 pixels = q*OW + r per row segment (simple_adv: one image wrap at most)
   int stagger;       // 1 = ping-pong schedule of the pipe kernel (WSEG_WGRAD_STAGGER; off: its read slots — 24/8/16/0 transposed
                      //     reads + pixel addressing — are longer and less even than an MFMA slot, the stagger then costs time)
   int diag;          // 0 = normal; timing diagnostics (WSEG_WGRAD_DIAG): 1 = no epilogue stores, 2 = plain stores
@@ -327,7 +328,14 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pipe_kernel(const Args a) {
       if (d.OH2 != 0 && xm[k] < M1 && mn >= M1) {     // crosses into the second segment: decode afresh (rare)
         const wseg_rowgeo rg = wseg_decode_row(d, min(mn, a.M - 1));
         xoy[k] = rg.oy; xox[k] = rg.ox; xbase[k] = (int)rg.in_base;
-      } else {
+      } else if (a.simple_adv) {                     // branch-free: 64 = q*OW + r (per segment, host-computed), at most one image wrap
+        int ox = xox[k] + (s2 ? a.r64_2 : a.r64_1), oy = xoy[k] + (s2 ? a.q64_2 : a.q64_1), bs = xbase[k];
+        const bool cx = ox >= OWs;
+        ox = cx ? ox - OWs : ox; oy = cx ? oy + 1 : oy;
+        const bool cy = oy >= OHs;
+        oy = cy ? oy - OHs : oy; bs = cy ? bs + IHs * IWs : bs;
+        xox[k] = ox; xoy[k] = oy; xbase[k] = bs;
+      } else {                                       // tiny maps (64 pixels span several images)
         int ox = xox[k] + PK, oy = xoy[k], bs = xbase[k];
         while (ox >= OWs) { ox -= OWs; ++oy; }
         while (oy >= OHs) { oy -= OHs; bs += IHs * IWs; }
@@ -579,6 +587,9 @@ extern "C" int wseg_conv_wgrad(const wseg_wgrad_desc* d, void* stream) {
   split = (int)((M + pps - 1) / pps);
   a.nsplit = split;
   a.nwg = a.ntiles * split;
+  a.q64_1 = 64 / d->OW; a.r64_1 = 64 % d->OW;
+  a.q64_2 = d->OH2 ? 64 / d->OW2 : 0; a.r64_2 = d->OH2 ? 64 % d->OW2 : 0;
+  a.simple_adv = (a.q64_1 + 1 <= d->OH) && (d->OH2 == 0 || a.q64_2 + 1 <= d->OH2);
   static const int diag = getenv("WSEG_WGRAD_DIAG") ? atoi(getenv("WSEG_WGRAD_DIAG")) : 0;
   a.diag = diag;
   static const int stagger = getenv("WSEG_WGRAD_STAGGER") ? atoi(getenv("WSEG_WGRAD_STAGGER")) : 2;   // (2 measured best: 14.06 vs 14.85 / 15.9 ms/step) 0/1: 4 phases lock-step / ping-pong (1 measured slower: 17.1 vs 14.8 ms/step); 2/3: 2 phases lock-step / ping-pong
