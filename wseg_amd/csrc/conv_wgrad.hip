@@ -256,7 +256,8 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void conv_wgrad_kernel(const Args 
 // and the only DMA wait is a counted s_waitcnt vmcnt(4) in p4.  One raw s_barrier per phase.  The transposed
 // fragment reads go through inline asm (hipcc would put vmcnt(0) in front of ds_read_tr builtins while
 // LDS-DMA is in flight), with an explicit lgkmcnt(0) + sched_barrier before the MFMAs.
-template <int SCHED>   // 0/1: 4 phases lock-step / ping-pong; 2/3: 2 phases lock-step / ping-pong
+template <int SCHED, int UNIT>   // SCHED 0/1: 4 phases lock-step / ping-pong; 2/3: 2 phases lock-step / ping-pong
+                                 // UNIT 1: stride 1 and IH==OH, IW==OW in both segments (the X source row is m + const)
 __global__ __launch_bounds__(512, 2) void conv_wgrad_pipe_kernel(const Args a) {
   constexpr int BO = 256, BI = 256, NT = 512;
   constexpr int PK = 64, HALF = 16384, TILE = 4 * HALF, ROWB = 256;
@@ -311,11 +312,44 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pipe_kernel(const Args a) {
   const bool yok[2][2] = {{oc0 + lc[0] * 8 < d.OC, oc0 + 128 + lc[0] * 8 < d.OC}, {oc0 + lc[1] * 8 < d.OC, oc0 + 128 + lc[1] * 8 < d.OC}};
   const bool xok[2][2] = {{ic0 + lc[0] * 8 < d.IC, ic0 + 128 + lc[0] * 8 < d.IC}, {ic0 + lc[1] * 8 < d.IC, ic0 + 128 + lc[1] * 8 < d.IC}};
   const char* xrow[2];                               // source pixel row (chunk lc[k], half 0) of the X tile being issued, or nullptr
+  // UNIT geometry: input pixel of (output row m, tap) = m + dy*W + dx inside its segment, so the source pointer is a running
+  // pointer (+64 rows per K-tile, + a constant when crossing into the second segment) and only the VALIDITY needs (oy, ox).
+  const int dy = ky * d.dil - d.pad, dx = kx * d.dil - d.pad;
+  const char* xptr[2];
+  if constexpr (UNIT) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const bool s2 = d.OH2 != 0 && xm[k] >= M1;
+      const long shift = (long)dy * (s2 ? d.IW2 : d.IW) + dx;
+      xptr[k] = X + (((long)xm[k] + shift) * d.ld_x + ic0 + lc[k] * 8) * 2;
+    }
+  }
+  const size_t xstep = (size_t)PK * d.ld_x * 2;
+  const long xcross = (long)dy * (d.IW2 - d.IW) * d.ld_x * 2;      // pointer correction when a row enters segment 2
   auto x_prepare = [&]() {                           // call once per X tile, before its two half issues; advances to the next tile
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const bool s2 = d.OH2 != 0 && xm[k] >= M1;
       const int OHs = s2 ? d.OH2 : d.OH, OWs = s2 ? d.OW2 : d.OW, IHs = s2 ? d.IH2 : d.IH, IWs = s2 ? d.IW2 : d.IW;
+      const int mn = xm[k] + PK;
+      if constexpr (UNIT) {
+        const bool ok = xm[k] < m_end && (unsigned)(xoy[k] + dy) < (unsigned)OHs && (unsigned)(xox[k] + dx) < (unsigned)OWs;
+        xrow[k] = ok ? xptr[k] : nullptr;
+        xptr[k] += xstep;
+        if (d.OH2 != 0 && xm[k] < M1 && mn >= M1) {   // crosses into the second segment (rare): new coordinates, new tap shift
+          const wseg_rowgeo rg = wseg_decode_row(d, min(mn, a.M - 1));
+          xoy[k] = rg.oy; xox[k] = rg.ox;
+          xptr[k] += xcross;
+        } else {                                     // branch-free (host guarantees one row wrap at most: simple_adv)
+          int ox = xox[k] + (s2 ? a.r64_2 : a.r64_1), oy = xoy[k] + (s2 ? a.q64_2 : a.q64_1);
+          const bool cx = ox >= OWs;
+          ox = cx ? ox - OWs : ox; oy = cx ? oy + 1 : oy;
+          oy = oy >= OHs ? oy - OHs : oy;
+          xox[k] = ox; xoy[k] = oy;
+        }
+        xm[k] = mn;
+        continue;
+      }
       xrow[k] = nullptr;
       if (xm[k] < m_end) {
         const int iy = xoy[k] * d.stride + ky * d.dil - d.pad;
@@ -324,7 +358,6 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pipe_kernel(const Args a) {
           xrow[k] = X + ((size_t)(xbase[k] + iy * IWs + ix) * d.ld_x + ic0 + lc[k] * 8) * 2;
       }
       // advance 64 pixel rows
-      const int mn = xm[k] + PK;
       if (d.OH2 != 0 && xm[k] < M1 && mn >= M1) {     // crosses into the second segment: decode afresh (rare)
         const wseg_rowgeo rg = wseg_decode_row(d, min(mn, a.M - 1));
         xoy[k] = rg.oy; xox[k] = rg.ox; xbase[k] = (int)rg.in_base;
@@ -598,10 +631,14 @@ extern "C" int wseg_conv_wgrad(const wseg_wgrad_desc* d, void* stream) {
   dim3 grid(a.nwg);
   static const bool use_pipe = !(getenv("WSEG_WGRAD_PIPE") && getenv("WSEG_WGRAD_PIPE")[0] == '0');
   if (big && use_pipe) {
-    if (stagger == 3) hipLaunchKernelGGL(conv_wgrad_pipe_kernel<3>, grid, dim3(512), 0, s, a);
-    else if (stagger == 2) hipLaunchKernelGGL(conv_wgrad_pipe_kernel<2>, grid, dim3(512), 0, s, a);
-    else if (stagger == 1) hipLaunchKernelGGL(conv_wgrad_pipe_kernel<1>, grid, dim3(512), 0, s, a);
-    else hipLaunchKernelGGL(conv_wgrad_pipe_kernel<0>, grid, dim3(512), 0, s, a);
+    static const int unit_ok = getenv("WSEG_WGRAD_UNIT") ? atoi(getenv("WSEG_WGRAD_UNIT")) : 1;
+    const bool unit = unit_ok && a.simple_adv && d->stride == 1 && d->IH == d->OH && d->IW == d->OW &&
+                      (d->OH2 == 0 || (d->IH2 == d->OH2 && d->IW2 == d->OW2));
+    if (stagger == 3) hipLaunchKernelGGL((conv_wgrad_pipe_kernel<3, 0>), grid, dim3(512), 0, s, a);
+    else if (stagger == 1) hipLaunchKernelGGL((conv_wgrad_pipe_kernel<1, 0>), grid, dim3(512), 0, s, a);
+    else if (stagger == 0) hipLaunchKernelGGL((conv_wgrad_pipe_kernel<0, 0>), grid, dim3(512), 0, s, a);
+    else if (unit) hipLaunchKernelGGL((conv_wgrad_pipe_kernel<2, 1>), grid, dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((conv_wgrad_pipe_kernel<2, 0>), grid, dim3(512), 0, s, a);
   }
   else if (big)
     hipLaunchKernelGGL((conv_wgrad_kernel<WSEG_BF16, 256, 256, 2, 4>), grid, dim3(512), 0, s, a);
