@@ -17,9 +17,16 @@
 // Partial tiles are added to the f32 dW with 256-B-contiguous float atomics.
 #include <stdlib.h>
 #include <algorithm>
+#include <type_traits>
 #include "common.h"
 
 namespace {
+
+// transposed LDS read with a compile-time immediate offset (ds_read_b64_tr_b16: 4 pixels x 16 channels per 16-lane group)
+template <int OFF>
+__device__ __forceinline__ void tr_read(bf16x4& dst, unsigned addr) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
 
 struct Args {
   wseg_wgrad_desc d;
@@ -286,6 +293,9 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pipe_kernel(const Args a) {
   const char* X = reinterpret_cast<const char*>(d.x);
   const char* DY = reinterpret_cast<const char*>(d.dy);
 
+  // LDS slot (buffer buf, half-tile which = dY0, dY1, X0, X1).  The 2-phase schedules interleave the two buffers at slot
+  // granularity so that the buffer offset fits the ds_read immediate (all transposed reads then need no address VALU).
+  auto slot_off = [](int buf, int which) { return SCHED >= 2 ? (which * 2 + buf) * HALF : buf * TILE + which * HALF; };
   // staging: thread -> rows r0 = tid>>4 and r0+32 of every half-tile, physical 16-B chunk tid&15.
   // All per-K-tile address work is INCREMENTAL (this loop is VALU-sensitive: 64 MFMAs per wave per K-tile leave
   // ~250 issue slots): dY pointers advance by a constant; the X pixel coordinates (n, oy, ox) advance by 64 rows
@@ -378,7 +388,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pipe_kernel(const Args a) {
     }
   };
   auto issue_x = [&](int h, int buf) {
-    char* dst = smem + buf * TILE + (2 + h) * HALF + wid * 1024;
+    char* dst = smem + slot_off(buf, 2 + h) + wid * 1024;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const char* p = (xrow[k] && xok[k][h]) ? xrow[k] + h * 256 : zsrc;
@@ -386,7 +396,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pipe_kernel(const Args a) {
     }
   };
   auto issue_y = [&](int h, int buf) {               // half h of the NEXT Y tile; h == 1 advances to the following tile
-    char* dst = smem + buf * TILE + h * HALF + wid * 1024;
+    char* dst = smem + slot_off(buf, h) + wid * 1024;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const char* p = (my[k] < m_end && yok[k][h]) ? ybase[k] + h * 256 : zsrc;
@@ -462,13 +472,34 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pipe_kernel(const Args a) {
     // other feeds the matrix pipe for 512 cycles.  Refills: dY0/dY1(u+1) in R1, X0/X1(u+2) + the counted wait in R2 — a
     // slot's last reader (the late group's read slot) is always one barrier before the early group's next issue into it.
     constexpr bool stg = SCHED == 3;
-    if (stg && wr == 1) asm volatile("s_barrier" ::: "memory");
-    for (int u = 0; u < nt; ++u) {
-      const int b = u & 1;
-      const unsigned abase = lds0 + b * TILE + wr * HALF;
-      const unsigned bbase = lds0 + b * TILE + (2 + (wc >> 1)) * HALF;
+    // transposed-read addresses = persistent lane term + immediate: the lane's row (fk*8+q) and 8-B column (p) plus the
+    // swizzled 32-B block (t ^ s) — s = q | (fk&1)<<2 does not depend on (ks, h) — and the slot of its wave; the buffer
+    // (b*HALF) and the (ks, h) row offsets (ks*32 + h*4 rows) are compile-time immediates.  12 registers, no VALU per read.
+    unsigned LTA[8], LTB[4];
+    {
+      const unsigned s_ = (unsigned)q | (((unsigned)fk & 1u) << 2);
+      const unsigned rowterm = lds0 + (unsigned)(fk * 8 + q) * ROWB + (unsigned)p * 8;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) LTA[t] = rowterm + (((unsigned)t ^ s_) << 5) + (unsigned)(wr * 2) * HALF;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) LTB[t] = rowterm + (((unsigned)((wc & 1) * 4 + t) ^ s_) << 5) + (unsigned)((2 + (wc >> 1)) * 2) * HALF;
+    }
+    auto ktile = [&](auto BC, int u) {
+      constexpr int b = decltype(BC)::value;
+      constexpr int BO = b * HALF;
       // ---- R1 / M1: rows 0-63 x all 64 columns
-      LOAD_A(0) LOAD_B(0, vb0) LOAD_B(1, vb1)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        tr_read<BO + 0>(va[0][0][i], LTA[i]); tr_read<BO + 1024>(va[0][1][i], LTA[i]);
+        tr_read<BO + 8192>(va[1][0][i], LTA[i]); tr_read<BO + 9216>(va[1][1][i], LTA[i]);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        tr_read<BO + 0>(vb0[0][0][j], LTB[j]); tr_read<BO + 1024>(vb0[0][1][j], LTB[j]);
+        tr_read<BO + 8192>(vb0[1][0][j], LTB[j]); tr_read<BO + 9216>(vb0[1][1][j], LTB[j]);
+        tr_read<BO + 0>(vb1[0][0][j], LTB[2 + j]); tr_read<BO + 1024>(vb1[0][1][j], LTB[2 + j]);
+        tr_read<BO + 8192>(vb1[1][0][j], LTB[2 + j]); tr_read<BO + 9216>(vb1[1][1][j], LTB[2 + j]);
+      }
       if (u + 1 < nt) { issue_y(0, b ^ 1); issue_y(1, b ^ 1); }
       if (stg) asm volatile("s_barrier" ::: "memory");
       WAIT_LDS();
@@ -477,7 +508,11 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pipe_kernel(const Args a) {
       MFMA_Q(0, 1, b1);
       asm volatile("s_barrier" ::: "memory");
       // ---- R2 / M2: rows 64-127; the counted wait publishes tile u+1 (only X0/X1(u+2) may stay in flight)
-      LOAD_A(1)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        tr_read<BO + 0>(va[0][0][i], LTA[4 + i]); tr_read<BO + 1024>(va[0][1][i], LTA[4 + i]);
+        tr_read<BO + 8192>(va[1][0][i], LTA[4 + i]); tr_read<BO + 9216>(va[1][1][i], LTA[4 + i]);
+      }
       if (u + 2 < nt) { x_prepare(); issue_x(0, b); issue_x(1, b); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (stg) asm volatile("s_barrier" ::: "memory");
@@ -486,7 +521,14 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pipe_kernel(const Args a) {
       MFMA_Q(1, 1, b1);
       MFMA_Q(1, 0, b0);
       asm volatile("s_barrier" ::: "memory");
+    };
+    if (stg && wr == 1) asm volatile("s_barrier" ::: "memory");
+    int u = 0;
+    for (; u + 1 < nt; u += 2) {
+      ktile(std::integral_constant<int, 0>{}, u);
+      ktile(std::integral_constant<int, 1>{}, u + 1);
     }
+    if (u < nt) ktile(std::integral_constant<int, 0>{}, u);
     if (stg && wr == 0) asm volatile("s_barrier" ::: "memory");
   } else {
   // Ping-pong schedule (see conv_igemm256_kernel): waves 4-7 (wr = 1, the second wave of every SIMD) run one slot
@@ -634,7 +676,8 @@ extern "C" int wseg_conv_wgrad(const wseg_wgrad_desc* d, void* stream) {
     static const int unit_ok = getenv("WSEG_WGRAD_UNIT") ? atoi(getenv("WSEG_WGRAD_UNIT")) : 1;
     const bool unit = unit_ok && a.simple_adv && d->stride == 1 && d->IH == d->OH && d->IW == d->OW &&
                       (d->OH2 == 0 || (d->IH2 == d->OH2 && d->IW2 == d->OW2));
-    if (stagger == 3) hipLaunchKernelGGL((conv_wgrad_pipe_kernel<3, 0>), grid, dim3(512), 0, s, a);
+    if (stagger == 3 && unit) hipLaunchKernelGGL((conv_wgrad_pipe_kernel<3, 1>), grid, dim3(512), 0, s, a);
+    else if (stagger == 3) hipLaunchKernelGGL((conv_wgrad_pipe_kernel<3, 0>), grid, dim3(512), 0, s, a);
     else if (stagger == 1) hipLaunchKernelGGL((conv_wgrad_pipe_kernel<1, 0>), grid, dim3(512), 0, s, a);
     else if (stagger == 0) hipLaunchKernelGGL((conv_wgrad_pipe_kernel<0, 0>), grid, dim3(512), 0, s, a);
     else if (unit) hipLaunchKernelGGL((conv_wgrad_pipe_kernel<2, 1>), grid, dim3(512), 0, s, a);
