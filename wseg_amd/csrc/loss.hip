@@ -120,19 +120,21 @@ __device__ __forceinline__ float key2f(unsigned k) { unsigned u = (k & 0x8000000
 // state[row] = {prefix, mask, k_remaining}; one pass handles 8 bits (shift = 24,16,8,0)
 __global__ __launch_bounds__(256) void select_hist_kernel(const float* __restrict__ vals, int n, int use_abs, const unsigned* __restrict__ state,
                                                           unsigned* __restrict__ hist, int shift) {
-  __shared__ unsigned h[256];
-  const int row = blockIdx.y;
-  h[threadIdx.x] = 0;
+  __shared__ unsigned h[4][256];                            // one sub-histogram per wave: values cluster, LDS atomics on one
+  const int row = blockIdx.y, wv = threadIdx.x >> 6;        // bucket serialise
+#pragma unroll
+  for (int w = 0; w < 4; ++w) h[w][threadIdx.x] = 0;
   __syncthreads();
   const unsigned prefix = state[row * 4 + 0], mask = state[row * 4 + 1];
   const float* v = vals + (size_t)row * n;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     float f = v[i]; if (use_abs) f = fabsf(f);
     const unsigned k = f2key(f);
-    if ((k & mask) == prefix) atomicAdd(&h[(k >> shift) & 255u], 1u);
+    if ((k & mask) == prefix) atomicAdd(&h[wv][(k >> shift) & 255u], 1u);
   }
   __syncthreads();
-  if (h[threadIdx.x]) atomicAdd(&hist[row * 256 + threadIdx.x], h[threadIdx.x]);
+  const unsigned t = h[0][threadIdx.x] + h[1][threadIdx.x] + h[2][threadIdx.x] + h[3][threadIdx.x];
+  if (t) atomicAdd(&hist[row * 256 + threadIdx.x], t);
 }
 // choose the bucket holding the k-th (k counted from the small end: 1-based rank) and narrow the prefix.
 // One wave per row: lane l owns buckets 4l..4l+3, a shuffle scan finds the lane whose running count crosses k.
@@ -466,15 +468,21 @@ __global__ __launch_bounds__(256) void proto_candidates_kernel(const float* __re
     if (tid < K) sel[tid] = tie_idx[tid];
     __syncthreads();
   } else {
-    for (int k = 0; k < K; ++k) {                          // K rounds of (max value, lowest index)
+    for (int k = 0; k < K; ++k) {                          // K rounds of (max value, lowest index): wave shuffles + one LDS hop
       float bv = -INFINITY; int bi = 0x7fffffff;
       for (int p = tid; p < P; p += 256) { const float v = sv[p]; if (v > bv || (v == bv && p < bi)) { bv = v; bi = p; } }
-      r_v[tid] = bv; r_i[tid] = bi; __syncthreads();
-      for (int o = 128; o > 0; o >>= 1) {
-        if (tid < o) { if (r_v[tid + o] > r_v[tid] || (r_v[tid + o] == r_v[tid] && r_i[tid + o] < r_i[tid])) { r_v[tid] = r_v[tid + o]; r_i[tid] = r_i[tid + o]; } }
-        __syncthreads();
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
       }
-      if (tid == 0) { sel[k] = r_i[0]; sv[r_i[0]] = -INFINITY; }
+      if ((tid & 63) == 0) { r_v[tid >> 6] = bv; r_i[tid >> 6] = bi; }
+      __syncthreads();
+      if (tid == 0) {
+#pragma unroll
+        for (int w = 1; w < 4; ++w) if (r_v[w] > bv || (r_v[w] == bv && r_i[w] < bi)) { bv = r_v[w]; bi = r_i[w]; }
+        sel[k] = bi; sv[bi] = -INFINITY;
+      }
       __syncthreads();
     }
   }
@@ -882,7 +890,7 @@ extern "C" int wseg_select_kth(const float* vals, int rows, int n, int k, int la
   unsigned* hist = state + (size_t)rows * 4;
   const unsigned rank_small = largest ? (unsigned)(n - k + 1) : (unsigned)k;
   hipLaunchKernelGGL(select_init_kernel, dim3((rows * 256 + 255) / 256), dim3(256), 0, ST, state, hist, rows, rank_small);
-  const int gx = std::min(256, (n + 2047) / 2048);
+  const int gx = std::max(1, std::min(32, (n + 8191) / 8192));   // few workgroups per row: their partials meet in same-address atomics
   for (int shift = 24; shift >= 0; shift -= 8) {
     hipLaunchKernelGGL(select_hist_kernel, dim3(gx, rows), dim3(256), 0, ST, vals, n, use_abs, state, hist, shift);
     hipLaunchKernelGGL(select_scan_kernel, dim3(rows), dim3(64), 0, ST, state, hist, shift, rows);

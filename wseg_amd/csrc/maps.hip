@@ -337,7 +337,9 @@ extern "C" int wseg_up_maps_backward(const float* G, const float* low, const flo
   WSEG_CHECK(plane_bias == nullptr || (wvec_y && wvec_x), "up_maps_backward: plane_bias needs the adjoint-of-ones vectors");
   WSEG_CHECK(q == nullptr || (argc && res), "up_maps_backward: q needs argc and res");
   (void)hipMemsetAsync(d_low, 0, sizeof(float) * (size_t)N * 21 * h * w, ST);
-  const int chunks = std::max(1, std::min(16, (S * S) / 8192));
+  // (many short chunks: the selection loop of a workgroup is a latency chain of divergent LDS scatters — measured 180 us
+  //  per launch with 8-12 iterations per workgroup, independent of the map size)
+  const int chunks = std::max(1, std::min(64, (S * S) / 2048));
   hipLaunchKernelGGL(up_maps_bwd_kernel, dim3((unsigned)(N * 21 * chunks)), dim3(256), (size_t)h * w * 4, ST, G, low, stats, label20, plane_bias,
                      wvec_y, wvec_x, q, argc, res, k, coef, d_low, h, w, S, OS, chunks);
   WSEG_LAUNCH_CHECK();
