@@ -183,7 +183,7 @@ int wseg_plane_stats(const float* U, float* stats, long planes, int npix, void* 
  *  up_maps_backward        d_low[pl] = all gradients of plane pl: max_norm + resize backward of G (NULL: none) with the
  *                          max/min routes, plane_bias[pl]*wvec_y*wvec_x (NULL: none), and the min-pool selection
  *                          (q/argc/res of select_kth, NULL: none; k, coef as in rvmin_backward). */
-int wseg_up_plane_stats(const float* low, float* stats, long planes, int h, int w, int S, void* workspace, void* stream);
+int wseg_up_plane_stats(const float* low, float* stats, long planes, int h, int w, int S, const float* label20 /* nullable: all planes; else only bg + labelled classes of [N][20] */, void* workspace, void* stream);
 int wseg_up_rvmin_values(const float* low, const float* label20, float* q, unsigned char* argc, int N, int h, int w, int S, void* stream);
 int wseg_up_norm_resize_forward(const float* low, const float* stats, const float* label20, float* out, int N, int h, int w, int S, int OS, void* stream);
 int wseg_resize_adjoint_ones(float* wvec, int h, int S, void* stream);

@@ -267,9 +267,9 @@ def nce_loss_grad(fn, nrm, S_own, S_oth, y_own, y_oth, w_intra, p_own, p_oth, dF
 
 
 # ---- SEAM map losses evaluated on the fly from the stride-8 maps (csrc/maps.hip): no [N,21,S,S] tensors
-def up_plane_stats(low, stats, planes, h, w, S):
+def up_plane_stats(low, stats, planes, h, w, S, label20=None):
     ws = torch.empty(int(lib.wseg_plane_stats_workspace_bytes(C.c_long(planes))), device=low.device, dtype=torch.uint8)
-    _call("wseg_up_plane_stats", _v(low), _v(stats), C.c_long(planes), h, w, S, _v(ws))
+    _call("wseg_up_plane_stats", _v(low), _v(stats), C.c_long(planes), h, w, S, _v(label20), _v(ws))
 def up_rvmin_values(low, label20, q, argc, N, h, w, S): _call("wseg_up_rvmin_values", _v(low), _v(label20), _v(q), _v(argc), N, h, w, S)
 def up_norm_resize_forward(low, stats, label20, out, N, h, w, S, OS): _call("wseg_up_norm_resize_forward", _v(low), _v(stats), _v(label20), _v(out), N, h, w, S, OS)
 def resize_adjoint_ones(wvec, h, S): _call("wseg_resize_adjoint_ones", _v(wvec), h, S)

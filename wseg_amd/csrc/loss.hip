@@ -890,13 +890,14 @@ extern "C" int wseg_select_kth(const float* vals, int rows, int n, int k, int la
   unsigned* hist = state + (size_t)rows * 4;
   const unsigned rank_small = largest ? (unsigned)(n - k + 1) : (unsigned)k;
   hipLaunchKernelGGL(select_init_kernel, dim3((rows * 256 + 255) / 256), dim3(256), 0, ST, state, hist, rows, rank_small);
-  const int gx = std::max(1, std::min(32, (n + 8191) / 8192));   // few workgroups per row: their partials meet in same-address atomics
+  const int gx = std::max(1, std::min(128, (n + 2047) / 2048));  // histogram passes: enough workgroups to stream the rows
+  const int gs = std::max(1, std::min(16, (n + 8191) / 8192));   // final sums: few workgroups per row (their partials meet in same-address atomics)
   for (int shift = 24; shift >= 0; shift -= 8) {
     hipLaunchKernelGGL(select_hist_kernel, dim3(gx, rows), dim3(256), 0, ST, vals, n, use_abs, state, hist, shift);
     hipLaunchKernelGGL(select_scan_kernel, dim3(rows), dim3(64), 0, ST, state, hist, shift, rows);
   }
   (void)hipMemsetAsync(res, 0, sizeof(float) * 4 * rows, ST);
-  hipLaunchKernelGGL(select_sum_kernel, dim3(gx, rows), dim3(256), 0, ST, vals, n, use_abs, largest, relu_vals, state, res);
+  hipLaunchKernelGGL(select_sum_kernel, dim3(gs, rows), dim3(256), 0, ST, vals, n, use_abs, largest, relu_vals, state, res);
   WSEG_LAUNCH_CHECK();
   return 0;
 }

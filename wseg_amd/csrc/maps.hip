@@ -56,10 +56,14 @@ __device__ __forceinline__ int threads_per_row(int S) { return S > 128 ? 256 : (
 // A plane is split over `chunks` row ranges; partials meet in packed 64-bit atomics (see loss.hip plane_stats).
 __global__ __launch_bounds__(256) void up_stats_partial_kernel(const float* __restrict__ low, unsigned long long* __restrict__ kmax,
                                                               unsigned long long* __restrict__ kmin, float* __restrict__ ksum,
-                                                              int h, int w, int S, int chunks) {
+                                                              int h, int w, int S, int chunks, const float* __restrict__ label20) {
   __shared__ unsigned long long s_mx[256], s_mn[256];
   __shared__ float s_sum[256];
   const int pl = blockIdx.x / chunks, ck = blockIdx.x - pl * chunks, tid = threadIdx.x;
+  if (label20) {                                  // only labelled planes (+ bg) are needed: the others' statistics are never read
+    const int c = pl % 21;
+    if (c >= 1 && label20[(pl / 21) * 20 + c - 1] == 0.f) return;
+  }
   const float* p = low + (size_t)pl * h * w;
   const float sy = ac_scale(h, S), sx = ac_scale(w, S);
   const int per = (S + chunks - 1) / chunks;
@@ -291,7 +295,7 @@ __global__ __launch_bounds__(256) void up_maps_bwd_kernel(const float* __restric
 #define ST ((hipStream_t)stream)
 
 // workspace: planes * 24 bytes (wseg_plane_stats_workspace_bytes)
-extern "C" int wseg_up_plane_stats(const float* low, float* stats, long planes, int h, int w, int S, void* workspace, void* stream) {
+extern "C" int wseg_up_plane_stats(const float* low, float* stats, long planes, int h, int w, int S, const float* label20, void* workspace, void* stream) {
   WSEG_CHECK(low && stats && workspace && planes > 0 && h > 0 && w > 0 && S > 0 && S <= 32768, "up_plane_stats: bad arguments");
   unsigned long long* kmax = (unsigned long long*)workspace;
   unsigned long long* kmin = kmax + planes;
@@ -300,7 +304,7 @@ extern "C" int wseg_up_plane_stats(const float* low, float* stats, long planes, 
   (void)hipMemsetAsync(kmin, 0xFF, sizeof(unsigned long long) * planes, ST);
   (void)hipMemsetAsync(ksum, 0x00, sizeof(float) * planes, ST);
   const int chunks = std::max(1, std::min(std::min(16, S / 16), (int)std::max(1L, 4096 / planes)));
-  hipLaunchKernelGGL(up_stats_partial_kernel, dim3((unsigned)(planes * chunks)), dim3(256), 0, ST, low, kmax, kmin, ksum, h, w, S, chunks);
+  hipLaunchKernelGGL(up_stats_partial_kernel, dim3((unsigned)(planes * chunks)), dim3(256), 0, ST, low, kmax, kmin, ksum, h, w, S, chunks, label20);
   hipLaunchKernelGGL(up_stats_final_kernel, dim3((unsigned)((planes + 255) / 256)), dim3(256), 0, ST, kmax, kmin, ksum, stats, planes);
   WSEG_LAUNCH_CHECK();
   return 0;

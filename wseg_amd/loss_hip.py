@@ -73,7 +73,7 @@ def _maps_forward(v, label20, acc, N):
     v.st_cam = _f32(N * 21, 6, dev=dev)
     v.st_rv = _f32(N * 21, 6, dev=dev)
     L.up_plane_stats(v.cam_low, v.st_cam, N * 21, h, w, S)
-    L.up_plane_stats(v.rvd, v.st_rv, N * 21, h, w, S)
+    L.up_plane_stats(v.rvd, v.st_rv, N * 21, h, w, S, label20)        # (max/min of labelled planes only; no GAP on this map)
     v.bias = _f32(N * 21, dev=dev)
     L.cls_loss(v.st_cam, label20, acc[0:1], v.bias, N, npix, 0.5)
     v.q = _f32(N, npix, dev=dev)
@@ -207,7 +207,9 @@ def step(model, img1, img2, label20, bg_threshold=0.20, rng=None, rng_parity=Fal
         v.fn, v.nrm = _f32(P, 128, dev=dev), _f32(P, dev=dev)
         v.S_own, v.S_oth = _f32(P, 21, dev=dev), _f32(P, 21, dev=dev)
         L.nce_sims(v.F, v.protos, o.protos, v.fn, v.nrm, v.S_own, v.S_oth, P)
-    global_intra = world > 1 or os.environ.get("WSEG_INTRA_GLOBAL", "0") == "1"
+    # (the radix-select kernel is also the faster one on a single rank — 47 vs 118 us; the sort-based kernel remains the
+    #  RNG-parity path, which replays the reference's host random stream)
+    global_intra = world > 1 or (not rng_parity and os.environ.get("WSEG_INTRA_GLOBAL", "1") == "1")
     if global_intra:
         # Hard-pixel sampling over the GLOBAL batch (the reference samples on the gathered batch): one
         # all-gather of {label, own-class similarity, random key} per pixel (96 KB per rank for both views); every rank
