@@ -120,7 +120,17 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void conv_wgrad_kernel(const Args 
     yok[i] = (oc0 + ylc[i] * CH) < d.OC;
   }
 
-  auto stage = [&](int buf, int mstep) {
+  // pixel coordinates of the X rows advance INCREMENTALLY by PK rows per stage (three integer divisions per piece per K-step
+  // made the small layers VALU-bound); a row that crosses into the second segment is decoded afresh
+  const int M1 = d.N * d.OH * d.OW;
+  int xm[PI], xoy[PI], xox[PI], xbase[PI];
+#pragma unroll
+  for (int i = 0; i < PI; ++i) {
+    xm[i] = m_begin + xr[i];
+    const wseg_rowgeo rg = wseg_decode_row(d, min(xm[i], a.M - 1));
+    xoy[i] = rg.oy; xox[i] = rg.ox; xbase[i] = (int)rg.in_base;
+  }
+  auto stage = [&](int buf, int mstep) {             // called with mstep = m_begin, m_begin + PK, ... (consecutive)
     char* lo = smem + buf * STAGE;
     char* li = lo + TILE_O;
 #pragma unroll
@@ -132,16 +142,27 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void conv_wgrad_kernel(const Args 
     }
 #pragma unroll
     for (int i = 0; i < PI; ++i) {
-      const int m = mstep + xr[i];
+      const bool s2 = d.OH2 != 0 && xm[i] >= M1;
+      const int OHs = s2 ? d.OH2 : d.OH, OWs = s2 ? d.OW2 : d.OW, IHs = s2 ? d.IH2 : d.IH, IWs = s2 ? d.IW2 : d.IW;
       const char* pi = zero + (lane & 15) * 16;
-      if (m < m_end && xok[i]) {
-        const wseg_rowgeo rg = wseg_decode_row(d, m);
-        const int iy = rg.oy * d.stride + ky * d.dil - d.pad;
-        const int ix = rg.ox * d.stride + kx * d.dil - d.pad;
-        if (iy >= 0 && iy < rg.IH && ix >= 0 && ix < rg.IW)
-          pi = X + ((size_t)(rg.in_base + (long)iy * rg.IW + ix) * d.ld_x + (size_t)(ic0 + xlc[i] * CH)) * ES;
+      if (xm[i] < m_end && xok[i]) {
+        const int iy = xoy[i] * d.stride + ky * d.dil - d.pad;
+        const int ix = xox[i] * d.stride + kx * d.dil - d.pad;
+        if (iy >= 0 && iy < IHs && ix >= 0 && ix < IWs)
+          pi = X + ((size_t)(xbase[i] + iy * IWs + ix) * d.ld_x + (size_t)(ic0 + xlc[i] * CH)) * ES;
       }
       glds16(pi, li + (wid * PI + i) * 1024);
+      const int mn = xm[i] + PK;
+      if (d.OH2 != 0 && xm[i] < M1 && mn >= M1) {
+        const wseg_rowgeo rg = wseg_decode_row(d, min(mn, a.M - 1));
+        xoy[i] = rg.oy; xox[i] = rg.ox; xbase[i] = (int)rg.in_base;
+      } else {
+        int ox = xox[i] + PK, oy = xoy[i], bs = xbase[i];
+        while (ox >= OWs) { ox -= OWs; ++oy; }
+        while (oy >= OHs) { oy -= OHs; bs += IHs * IWs; }
+        xox[i] = ox; xoy[i] = oy; xbase[i] = bs;
+      }
+      xm[i] = mn;
     }
   };
 
