@@ -162,15 +162,16 @@ def test_conv_many_row_tiles(dt):
     np.testing.assert_allclose(yg.float().cpu().numpy(), _nhwc(y).numpy(), **tol)
 
 
-@pytest.mark.parametrize("dt,bm", [("f32", 0), ("bf16", 0), ("bf16", 256)])
+@pytest.mark.parametrize("dt,bm", [("f32", 0), ("bf16", 0), ("bf16", 256), ("bf16", 2560)])
 @pytest.mark.parametrize("geom", [(3, 1, 2), (3, 2, 1), (1, 2, 1)])
 def test_conv_two_row_segments(dt, bm, geom):
     """Two views batched in one launch: rows [0,N*OH*OW) use geometry 1, the rest geometry 2 (fwd, dgrad, wgrad)."""
     from wseg_amd import _lib as L
     k, s, d = geom
     tdt = torch.float32 if dt == "f32" else torch.bfloat16
-    N, IC, OC = 2, (256 if bm == 256 else 64), 256      # bm=256: dgrad (OC = IC) takes the 256-tile kernel too
-    (H1, W1), (H2, W2) = (20, 18), (9, 11)
+    N, IC, OC = 2, (256 if bm >= 256 else 64), 256      # bm=256: dgrad (OC = IC) takes the 256-tile kernel too
+    (H1, W1), (H2, W2) = (20, 18), ((8, 12) if bm == 2560 else (9, 11))   # 2560: even sizes in both segments (parity-permuted s2 dgrad)
+    bm = min(bm, 256)
     pad = d * (k // 2)
     osz = lambda h: (h + 2 * pad - d * (k - 1) - 1) // s + 1
     xs = [_rand((N, IC, H1, W1), 1).to(tdt).float().requires_grad_(True), _rand((N, IC, H2, W2), 2).to(tdt).float().requires_grad_(True)]
@@ -211,6 +212,8 @@ CASES256 = [
     (2, 17, 15, 64, 256, 1, 2, 1),       # 1x1 stride 2, ONE K-tile (prologue-only pipeline)
     (1, 12, 12, 64, 256, 3, 1, 4),       # dilation 4 on a small map: most taps are padding
     (3, 9, 9, 128, 768, 3, 1, 1),        # 243 rows (< one tile), 3 column tiles
+    (2, 32, 28, 256, 256, 3, 2, 1),      # stride 2, even sizes: dgrad walks the rows in parity-class order (pure + mixed tiles)
+    (2, 24, 20, 256, 256, 1, 2, 1),      # 1x1 stride 2: three of the four parity classes have no tap at all
 ]
 
 

@@ -28,7 +28,34 @@ struct Args {
   int ntn;          // column tiles
   int nwg;
   int row0;         // first output row (pixel) of this launch (a launch may cover a row sub-range)
+  int perm;         // 256-tile kernel, stride-2 dgrad: rows are taken in PARITY-CLASS order (see perm_decode)
+  int Q1, Q2;       // rows per parity class in segment 1 / 2 (= N * OH/2 * OW/2)
 };
+
+// Stride-2 data gradient: an output pixel (y, x) only receives the taps with (y + pad - ky*dil) and (x + pad - kx*dil) even —
+// a quarter of the 3x3 taps on average, but consecutive pixels alternate parity, so a tile in natural row order needs every
+// tap (zero-page rows for the invalid ones: 4x wasted MFMA work).  The launch therefore walks the rows in parity-class order:
+// row m' = [segment][class (py,px)][n][i][j] <-> pixel (n, 2i+py, 2j+px); a tile that lies inside one class runs only that
+// class's taps.  Only the row <-> pixel bijection changes: gather addresses and the epilogue use the true pixel.
+struct PermRow { wseg_rowgeo g; int cls; long true_row; };
+__device__ __forceinline__ PermRow perm_decode(const Args& a, int m) {
+  const wseg_conv_desc& d = a.d;
+  PermRow r;
+  int rr = m, H = d.OH, W = d.OW, Q = a.Q1, seg = 0;
+  if (d.OH2 != 0 && rr >= 4 * a.Q1) { rr -= 4 * a.Q1; H = d.OH2; W = d.OW2; Q = a.Q2; seg = 1; }
+  const int cls = rr / Q, rem = rr - cls * Q;
+  const int hw2 = (H >> 1) * (W >> 1), w2 = W >> 1;
+  const int n = rem / hw2, rem2 = rem - n * hw2;
+  const int i = rem2 / w2, j = rem2 - i * w2;
+  r.g.oy = 2 * i + (cls >> 1); r.g.ox = 2 * j + (cls & 1);
+  r.g.n_glob = seg ? d.N + n : n;
+  r.g.IH = seg ? d.IH2 : d.IH; r.g.IW = seg ? d.IW2 : d.IW;
+  r.g.in_base = seg ? (long)d.N * d.IH * d.IW + (long)n * d.IH2 * d.IW2 : (long)n * d.IH * d.IW;
+  r.cls = seg * 4 + cls;
+  r.true_row = seg ? (long)d.N * d.OH * d.OW + ((long)n * H + r.g.oy) * W + r.g.ox : ((long)n * H + r.g.oy) * W + r.g.ox;
+  return r;
+}
+
 
 // Per-thread BN scale / shift of its 8-channel column group (1 / 0 when absent).
 __device__ __forceinline__ void epilogue_coeffs(const wseg_conv_desc& d, int n0, int cv, float (&sc)[8], float (&sh)[8]) {
@@ -359,7 +386,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const Args a) {
   for (int j = 0; j < 4; ++j) {
     const int m = m0 + r0 + 64 * j;
     if (m < a.M) {
-      const wseg_rowgeo rg = wseg_decode_row(d, m);
+      const wseg_rowgeo rg = a.perm ? perm_decode(a, m).g : wseg_decode_row(d, m);
       int iy0, ix0;
       if (d.mode == 0) { iy0 = rg.oy * d.stride - d.pad; ix0 = rg.ox * d.stride - d.pad; }
       else             { iy0 = rg.oy + d.pad;            ix0 = rg.ox + d.pad; }
@@ -369,9 +396,26 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const Args a) {
       a_base[j] = -1; a_yx[j] = (0x2000 << 16) | 0x2000;
     }
   }
+  // tap list (4-bit entries): all taps, or — parity-permuted rows, tile inside one class — only the class's valid taps
+  unsigned long long tl = 0x876543210ull;
+  int ntaps = a.taps;
+  if (a.perm) {
+    const int c0 = perm_decode(a, m0).cls, c1 = perm_decode(a, min(m0 + 255, a.M - 1)).cls;
+    if (c0 == c1) {
+      const int py = (c0 >> 1) & 1, px = c0 & 1;
+      tl = 0ull; ntaps = 0;
+      for (int t = 0; t < a.taps; ++t) {
+        const int ky = t / d.KW, kx = t - ky * d.KW;
+        if ((((py + d.pad - ky * d.dil) | (px + d.pad - kx * d.dil)) & 1) == 0) { tl |= (unsigned long long)t << (4 * ntaps); ++ntaps; }
+      }
+      if (ntaps == 0) { tl = 0ull; ntaps = 1; }    // (a class without taps: one all-padding tap keeps the pipeline uniform)
+    }
+  }
   const char* aptr[4];
   unsigned a_live = 0;                             // bit j: row j reads real data (pointer advances by 128 B per K-tile)
-  const char* bptr = Wp + ((size_t)(n0 + r0) * a.taps * d.IC + (size_t)lc * CH) * ES;   // OC % 256 == 0 (host-checked)
+  const char* bptr0 = Wp + ((size_t)(n0 + r0) * a.taps * d.IC + (size_t)lc * CH) * ES;   // OC % 256 == 0 (host-checked)
+  const char* bptr = bptr0 + (size_t)(tl & 15ull) * d.IC * ES;
+  int b_ti = 0, b_cc = 0;                          // (perm only) position of the NEXT B tile in the tap list
   const int brs = 64 * a.taps * d.IC * ES;         // bytes between B rows r0 + 64*j
   auto set_tap = [&](int tap) {
     const int ky = tap / d.KW, kx = tap - ky * d.KW;
@@ -404,14 +448,17 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const Args a) {
   auto advance_a = [&]() {
 #pragma unroll
     for (int j = 0; j < 4; ++j) aptr[j] += ((a_live >> j) & 1u) << 7;
-    if (++a_cc == a.cpt) { a_cc = 0; if (++a_tap < a.taps) set_tap(a_tap); }
+    if (++a_cc == a.cpt) { a_cc = 0; if (++a_tap < ntaps) set_tap((int)((tl >> (4 * a_tap)) & 15ull)); }
   };
   auto issue_b = [&](int h, int buf) {
     char* dst = smem + buf * TILE256 + (2 + h) * HALF256 + wid * 1024;
     glds16(bptr + (2 * h) * brs, dst);
     glds16(bptr + (2 * h + 1) * brs, dst + 8192);
   };
-  auto advance_b = [&]() { bptr += 128; };
+  auto advance_b = [&]() {
+    bptr += 128;                                   // (the full tap list is contiguous in K: nothing else to do)
+    if (a.perm && ++b_cc == a.cpt) { b_cc = 0; ++b_ti; bptr = bptr0 + (size_t)((tl >> (4 * b_ti)) & 15ull) * d.IC * ES; }
+  };
 
   f32x4 acc[8][4];
 #pragma unroll
@@ -419,9 +466,9 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const Args a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int nt = a.taps * a.cpt;
+  const int nt = ntaps * a.cpt;
   // prologue: tile 0 entirely + the B halves of tile 1 (what p3/p4 of a "tile -1" would have issued)
-  set_tap(0);
+  set_tap((int)(tl & 15ull));
   issue_a(0, 0); issue_a(1, 0); advance_a();
   issue_b(0, 0); issue_b(1, 0); advance_b();
   if (nt > 1) { issue_b(0, 1); issue_b(1, 1); advance_b(); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
@@ -567,7 +614,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const Args a) {
     for (int t = 0; t < 2; ++t) {
       const int m = m0 + wr * 128 + i * 16 + vr + 8 * t;
       ok[t] = col_ok && m < a.M;
-      mrow[t] = ok[t] ? (size_t)m : 0;
+      mrow[t] = ok[t] ? (a.perm ? (size_t)perm_decode(a, m).true_row : (size_t)m) : 0;
     }
     if (has_pre) {
 #pragma unroll
@@ -837,6 +884,7 @@ extern "C" int wseg_conv_igemm(const wseg_conv_desc* d, void* stream) {
   WSEG_CHECK(M < (1L << 31) && (long)d->N * d->IH * d->IW * d->ld_in < (1L << 40), "conv_igemm: tensor too large");
   Args a;
   a.d = *d;
+  a.perm = 0; a.Q1 = a.Q2 = 0;
   a.M = (int)M;
   a.taps = d->KH * d->KW;
   a.cpt = d->IC * es / ROWB;
@@ -884,6 +932,12 @@ extern "C" int wseg_conv_igemm(const wseg_conv_desc* d, void* stream) {
     else hipLaunchKernelGGL(conv_igemm256x128_kernel<2>, dim3(a.nwg), dim3(512), 0, s, a);
   } else if (big) {
     const int ntn128 = a.ntn;
+    static const int perm_ok = getenv("WSEG_CONV_PERM") ? atoi(getenv("WSEG_CONV_PERM")) : 1;
+    if (perm_ok && d->mode == 1 && d->stride == 2 && d->OH % 2 == 0 && d->OW % 2 == 0 && d->OH2 % 2 == 0 && d->OW2 % 2 == 0 && a.taps <= 9) {
+      a.perm = 1;
+      a.Q1 = d->N * (d->OH / 2) * (d->OW / 2);
+      a.Q2 = d->N * (d->OH2 / 2) * (d->OW2 / 2);
+    }
     a.ntn = (d->OC + 255) / 256;
     const long ntm = (M + 255) / 256;
     long main_tm = ntm;                              // row tiles given to the 256-tile kernel
@@ -892,7 +946,7 @@ extern "C" int wseg_conv_igemm(const wseg_conv_desc* d, void* stream) {
     // layers move +-8 % either way) — a partly filled last round runs faster per tile, rounds are not discrete here either.
     static const int split_tail = getenv("WSEG_CONV_SPLIT") ? atoi(getenv("WSEG_CONV_SPLIT")) : 0;
     const long t256 = ntm * a.ntn, full = t256 / 256, rem = t256 % 256;
-    if ((split_tail && d->bm_hint == 0 && full >= 1 && rem > 0 && rem <= 208 && 256 % a.ntn == 0) || d->bm_hint == 257)
+    if (!a.perm && ((split_tail && d->bm_hint == 0 && full >= 1 && rem > 0 && rem <= 208 && 256 % a.ntn == 0) || d->bm_hint == 257))
       main_tm = d->bm_hint == 257 ? std::max(1L, ntm / 2) : full * 256 / a.ntn;
     a.nwg = (int)(main_tm * a.ntn);
     static const int stagger = getenv("WSEG_CONV_STAGGER") ? atoi(getenv("WSEG_CONV_STAGGER")) : 2;   // 0: 4 phases lock-step, 1: 4 phases ping-pong, 2: 2 phases ping-pong (best), 3: 2 phases lock-step
