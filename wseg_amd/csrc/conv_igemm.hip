@@ -933,7 +933,8 @@ extern "C" int wseg_conv_igemm(const wseg_conv_desc* d, void* stream) {
   } else if (big) {
     const int ntn128 = a.ntn;
     static const int perm_ok = getenv("WSEG_CONV_PERM") ? atoi(getenv("WSEG_CONV_PERM")) : 1;
-    if (perm_ok && d->mode == 1 && d->stride == 2 && d->OH % 2 == 0 && d->OW % 2 == 0 && d->OH2 % 2 == 0 && d->OW2 % 2 == 0 && a.taps <= 9) {
+    if (perm_ok && d->mode == 1 && d->stride == 2 && d->OH % 2 == 0 && d->OW % 2 == 0 && d->OH2 % 2 == 0 && d->OW2 % 2 == 0 && a.taps <= 9 &&
+        (a.taps > 1 || d->bm_hint == 256)) {   // (1x1: nothing to skip in the K loop, the per-vector row mapping only costs — measured)
       a.perm = 1;
       a.Q1 = d->N * (d->OH / 2) * (d->OW / 2);
       a.Q2 = d->N * (d->OH2 / 2) * (d->OW2 / 2);
