@@ -205,7 +205,8 @@ int wseg_rows_resize_forward(const void* head, int ld, float* F, int N, int ih, 
 int wseg_head_grad_fused(const float* dF, const float* d_cam_low, const void* head, void* d_head, int ld, int N, int ih, int iw, int oh, int ow, int dtype, void* stream);
 int wseg_pseudo_label(const float* R, const float* label20, float bg_thr, int* y, float* ncam, int N, int npix, void* stream);
 int wseg_proto_candidates(const float* ncam, const float* F, const int* tie_idx, float* cand_val, float* cand_feat, int* cand_const, int N, int npix, int K, void* stream);
-int wseg_proto_merge(const float* cand_val, const float* cand_feat, const int* cand_const, float* protos, int world, int K, void* stream);
+int wseg_proto_merge(const float* cand_val, const float* cand_feat, const int* cand_const, float* protos, int world, int K,
+                     long rank_stride /* 0: contiguous [world][...] arrays; else elements between consecutive ranks' blocks (one gathered buffer) */, void* stream);
 int wseg_nce_sims(const float* F, const float* p_own, const float* p_oth, float* fn, float* nrm, float* S_own, float* S_oth, int P, void* stream);
 int wseg_intra_weights(const int* y, const float* S_own, const float* rkey, const unsigned char* rand_flag, float* w, int P, void* stream);
 /* the same sampling over the GLOBAL batch under data parallelism (the reference runs :302-334 on the gathered batch):

@@ -57,6 +57,17 @@ def test_prototype_exchange_two_ranks_on_one_gpu():
     ref = merge(rv[None], rf[None], rc[None])
     np.testing.assert_allclose(p1.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(p2.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-6)
+    # the product layout: ONE gathered buffer [world][2 views][block], this view's blocks a rank stride apart (loss_hip.py)
+    from wseg_amd.loss_hip import _CAND_L
+    gathered = torch.zeros(2, 2, _CAND_L, device=dev)
+    for w, (v_, f_, c_) in enumerate((a, b)):
+        blk = gathered[w, 1]
+        blk[:21 * K] = v_.reshape(-1); blk[21 * K:21 * K * 129] = f_.reshape(-1)
+        blk[21 * K * 129:21 * K * 129 + 21].view(torch.int32).copy_(c_)
+    base = gathered.view(-1)[_CAND_L:]
+    p3 = torch.empty(21, 128, device=dev)
+    L.proto_merge(base, base[21 * K:], base[21 * K * 129:].view(torch.int32), p3, 2, K, 2 * _CAND_L)
+    np.testing.assert_allclose(p3.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-6)
 
 
 def test_cli_plumbing_train_then_infer(tmp_path, monkeypatch):

@@ -257,7 +257,7 @@ def rows_resize_forward(head, ld, F, N, ih, iw, oh, ow): _call("wseg_rows_resize
 def head_grad_fused(dF, d_cam_low, head, d_head, ld, N, ih, iw, oh, ow): _call("wseg_head_grad_fused", _v(dF), _v(d_cam_low), _v(head), _v(d_head), ld, N, ih, iw, oh, ow, dtype_code(head))
 def pseudo_label(R, label20, bg_thr, y, ncam, N, npix): _call("wseg_pseudo_label", _v(R), _v(label20), _f(bg_thr), _v(y), _v(ncam), N, npix)
 def proto_candidates(ncam, F, tie_idx, cand_val, cand_feat, cand_const, N, npix, K): _call("wseg_proto_candidates", _v(ncam), _v(F), _v(tie_idx), _v(cand_val), _v(cand_feat), _v(cand_const), N, npix, K)
-def proto_merge(cand_val, cand_feat, cand_const, protos, world, K): _call("wseg_proto_merge", _v(cand_val), _v(cand_feat), _v(cand_const), _v(protos), world, K)
+def proto_merge(cand_val, cand_feat, cand_const, protos, world, K, rank_stride=0): _call("wseg_proto_merge", _v(cand_val), _v(cand_feat), _v(cand_const), _v(protos), world, K, C.c_long(rank_stride))
 def nce_sims(F, p_own, p_oth, fn, nrm, S_own, S_oth, P): _call("wseg_nce_sims", _v(F), _v(p_own), _v(p_oth), _v(fn), _v(nrm), _v(S_own), _v(S_oth), P)
 def intra_weights(y, S_own, rkey, rand_flag, w, P): _call("wseg_intra_weights", _v(y), _v(S_own), _v(rkey), _v(rand_flag), _v(w), P)
 def intra_pack(y, S_own, rkey, rec, P): _call("wseg_intra_pack", _v(y), _v(S_own), _v(rkey), _v(rec), P)

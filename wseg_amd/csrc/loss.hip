@@ -496,15 +496,15 @@ __global__ __launch_bounds__(256) void proto_candidates_kernel(const float* __re
 }
 // merge world*K candidates per class -> top K -> weighted mean -> L2 normalise (F.normalize eps 1e-12)
 __global__ __launch_bounds__(128) void proto_merge_kernel(const float* __restrict__ cand_val, const float* __restrict__ cand_feat, const int* __restrict__ cand_const,
-                                                          float* __restrict__ protos, int world, int K) {
+                                                          float* __restrict__ protos, int world, int K, long rs_val, long rs_feat, long rs_const) {
   __shared__ float vals[512]; __shared__ int order[64]; __shared__ float red[2];
   const int c = blockIdx.x, tid = threadIdx.x;
-  const int M = world * K;                                  // gathered layout: [world][21][K]
-  for (int i = tid; i < M; i += 128) { const int w = i / K, k = i - w * K; vals[i] = cand_val[((size_t)w * 21 + c) * K + k]; }
+  const int M = world * K;                                  // rank w's [21][K] values / [21][K][128] features / [21] flags at w * rs_*
+  for (int i = tid; i < M; i += 128) { const int w = i / K, k = i - w * K; vals[i] = cand_val[(size_t)w * rs_val + c * K + k]; }
   __syncthreads();
   if (tid == 0) {
     bool cst = true;
-    for (int w = 0; w < world; ++w) cst = cst && cand_const[w * 21 + c];
+    for (int w = 0; w < world; ++w) cst = cst && cand_const[(size_t)w * rs_const + c];
     if (cst) { for (int k = 0; k < K; ++k) order[k] = k; }  // fully tied: rank 0's set (global pixels first)
     else {
       for (int k = 0; k < K; ++k) {
@@ -518,8 +518,8 @@ __global__ __launch_bounds__(128) void proto_merge_kernel(const float* __restric
   float acc = 0.f, wsum = 0.f;
   for (int k = 0; k < K; ++k) {
     const int i = order[k]; const int w = i / K, kk = i - w * K;
-    const float v = cand_val[((size_t)w * 21 + c) * K + kk];
-    acc += v * cand_feat[(((size_t)w * 21 + c) * K + kk) * 128 + tid];
+    const float v = cand_val[(size_t)w * rs_val + c * K + kk];
+    acc += v * cand_feat[(size_t)w * rs_feat + ((size_t)c * K + kk) * 128 + tid];
     wsum += v;
   }
   const float pr = acc / wsum;
@@ -980,9 +980,12 @@ extern "C" int wseg_proto_candidates(const float* ncam, const float* F, const in
   WSEG_LAUNCH_CHECK();
   return 0;
 }
-extern "C" int wseg_proto_merge(const float* cand_val, const float* cand_feat, const int* cand_const, float* protos, int world, int K, void* stream) {
+extern "C" int wseg_proto_merge(const float* cand_val, const float* cand_feat, const int* cand_const, float* protos, int world, int K,
+                                long rank_stride, void* stream) {
   WSEG_CHECK(cand_val && cand_feat && cand_const && protos && world >= 1 && world * K <= 512 && K <= 64, "proto_merge: bad arguments");
-  hipLaunchKernelGGL(proto_merge_kernel, dim3(21), dim3(128), 0, ST, cand_val, cand_feat, cand_const, protos, world, K);
+  // rank_stride 0: contiguous [world][21][K] / [world][21][K][128] / [world][21]; else all three advance by rank_stride elements per rank
+  const long rv = rank_stride ? rank_stride : 21L * K, rf = rank_stride ? rank_stride : 21L * K * 128, rc = rank_stride ? rank_stride : 21L;
+  hipLaunchKernelGGL(proto_merge_kernel, dim3(21), dim3(128), 0, ST, cand_val, cand_feat, cand_const, protos, world, K, rv, rf, rc);
   WSEG_LAUNCH_CHECK();
   return 0;
 }

@@ -7,7 +7,7 @@ combination of a handful of device scalars.  No autograd graph is built.
 
 Global-batch semantics under data parallelism: the per-class top-32 prototype
 candidates (value + feature row) of every rank are all-gathered and merged, so every rank holds the
-prototypes the reference would compute over the whole batch; hard-pixel sampling (contrast_train.py
+prototypes the reference would compute over the whole batch (one all-gather for both views); hard-pixel sampling (contrast_train.py
 :302-331) exchanges one {label, similarity, random key} record per pixel, and every rank finds the same
 global per-class order statistics (csrc/loss.hip intra_weights_global).
 """
@@ -101,9 +101,16 @@ def _maps_backward(v, label20, N):
                        v.d_rvd, N, h, w, S, 128)
 
 
-def _prototypes(v, label20, bg_threshold, tie_idx, N, world):
+_CAND_K = 256 // 8                                           # top-32 per class (contrast_train.py:202)
+_CAND_L = 21 * _CAND_K * 129 + 32                            # one view's candidate block: [21][K] values | [21][K][128] features | [21] flags (+pad)
+
+
+def _candidates(v, label20, bg_threshold, tie_idx, N, block):
+    """Pseudo-labels and this rank's per-class top-32 prototype candidates of one view, written into `block` (a
+    _CAND_L-float slice of the exchange buffer)."""
     dev = v.cam_low.device
     P = N * 256
+    K = _CAND_K
     v.F = _f32(P, 128, dev=dev)
     L.rows_resize_forward(v.head, HEAD_LD, v.F, N, v.h, v.w, 16, 16)
     if (v.h, v.w) == (16, 16):
@@ -114,20 +121,17 @@ def _prototypes(v, label20, bg_threshold, tie_idx, N, world):
     v.y = torch.empty(P, device=dev, dtype=torch.int32)
     v.ncam = _f32(N, 21, 256, dev=dev)
     L.pseudo_label(R, label20, bg_threshold, v.y, v.ncam, N, 256)
-    K = 256 // 8
-    cv, cf = _f32(21, K, dev=dev), _f32(21, K, 128, dev=dev)
-    cc = torch.empty(21, device=dev, dtype=torch.int32)
+    cv, cf = block[:21 * K], block[21 * K:21 * K * 129]
+    cc = block[21 * K * 129:21 * K * 129 + 21].view(torch.int32)
     L.proto_candidates(v.ncam, v.F, tie_idx, cv, cf, cc, N, 256, K)
-    if world > 1:                                        # global-batch prototypes: exchange candidates over RCCL
-        gv, gf = _f32(world, 21, K, dev=dev), _f32(world, 21, K, 128, dev=dev)
-        gc = torch.empty(world, 21, device=dev, dtype=torch.int32)
-        # (outputs as dim-0 concatenations: the form both RCCL and gloo accept)
-        dist.all_gather_into_tensor(gv.view(world * 21, K), cv)
-        dist.all_gather_into_tensor(gf.view(world * 21, K, 128), cf)
-        dist.all_gather_into_tensor(gc.view(world * 21), cc)
-        cv, cf, cc = gv, gf, gc
-    v.protos = _f32(21, 128, dev=dev)
-    L.proto_merge(cv, cf, cc, v.protos, world, K)
+
+
+def _merge_prototypes(v, gathered, view_idx, world):
+    """Global-batch prototypes of one view from the gathered candidate blocks [world][2][_CAND_L] (every rank: same result)."""
+    K = _CAND_K
+    base = gathered.view(-1)[view_idx * _CAND_L:]
+    v.protos = _f32(21, 128, dev=gathered.device)
+    L.proto_merge(base, base[21 * K:], base[21 * K * 129:].view(torch.int32), v.protos, world, K, 2 * _CAND_L)
 
 
 def _rand_flags(y_dev, rng, P):
@@ -176,17 +180,20 @@ def step(model, img1, img2, label20, bg_threshold=0.20, rng=None, rng_parity=Fal
         views.append(v)
     v1, v2 = views
     # per view, on its own stream: map losses (cls, min-pool, max-norm maps), then pseudo-labels + prototype candidates
-    for v, st in zip(views, side):
+    cand = _f32(2, _CAND_L, dev=dev)
+    for vi, (v, st) in enumerate(zip(views, side)):
         st.wait_event(fork)
         with torch.cuda.stream(st):
             _maps_forward(v, label20, acc, N)
-            if world == 1:
-                _prototypes(v, label20, bg_threshold, tie_idx, N, world)
+            _candidates(v, label20, bg_threshold, tie_idx, N, cand[vi])
     for st in side:
         main.wait_stream(st)
-    if world > 1:                                           # collectives stay on the main stream, in program order
-        for v in views:
-            _prototypes(v, label20, bg_threshold, tie_idx, N, world)
+    gathered = cand
+    if world > 1:                                           # global-batch prototypes: ONE all-gather of both views' candidates (694 KB)
+        gathered = _f32(world, 2, _CAND_L, dev=dev)
+        dist.all_gather_into_tensor(gathered.view(world * 2, _CAND_L), cand)
+    for vi, v in enumerate(views):
+        _merge_prototypes(v, gathered, vi, world)
     # ---- ER + ECR on the 128x128 maps (both directions of the ECR top-k in ONE 2N-row selection)
     npix = 128 * 128
     er_coef = 1.0 / (N * 20 * npix)
