@@ -208,3 +208,60 @@ def test_intra_weights_global_matches_sorted_kernel(ranks):
         ref = w_ref[r * P:(r + 1) * P] * ranks
         assert float(ref.sum()) > 0
         assert torch.allclose(w, ref, rtol=1e-6, atol=0), float((w - ref).abs().max())
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_identical_views_property(proc_sd, prec):
+    """Size-independent identity of the reference's loss: with a 128x128 input the second view is the
+    first one (resize 128 -> 128 is the identity), so with the same dropout masks the two row segments of every batched
+    launch carry identical data: equivariant regularisation = 0, the two ECR directions and the two cross-view NCE terms
+    coincide.  Exercises the whole two-segment path (conv tiles straddling the segment boundary, prototypes, NCE)."""
+    from wseg_amd import synth
+    n, seed = 4, 5
+    model, opt, tr = _trainer(proc_sd, prec, "hip", n, seed, 3, lr=0.0)
+    m = synth.synthetic_dropout_masks(n, 77)
+    model.set_dropout_masks([m, {k: v.clone() for k, v in m.items()}])
+    got = tr.step(synth.synthetic_images(n, 128, seed).cuda(), synth.synthetic_labels(n, seed).cuda())
+    assert float(got["loss_er"]) <= 1e-7, float(got["loss_er"])
+    a, b = float(got["loss_cross_nce"]), float(got["loss_cross_nce2"])
+    assert abs(a - b) <= 1e-6 * max(1.0, abs(a)), (a, b)
+    for k in SCALARS:
+        assert np.isfinite(float(got[k])), k
+
+
+def test_full_size_step_properties(proc_sd):
+    """BASELINE config 2 at its full size (B=16 x 448 x 448, bf16): properties that need no oracle — the logged scalars are
+    finite and consistent (loss = cls + er + ecr + nce, nce = intra + cross + cross2), the step is repeatable (a second
+    identical step with lr = 0 gives the same scalars up to the order of float atomics in the reductions), every
+    trainable tensor receives a finite non-zero gradient and the frozen prefix none, and the fused SGD moves the weights."""
+    from wseg_amd import synth
+    n, seed = 16, 0
+    model, opt, tr = _trainer(proc_sd, "bf16", "hip", n, seed, 1, lr=0.0)
+    img, lab = synth.synthetic_images(n, 448, seed).cuda(), synth.synthetic_labels(n, seed).cuda()
+    masks = [synth.synthetic_dropout_masks(n, 10), synth.synthetic_dropout_masks(n, 11)]
+    model.set_dropout_masks([{k: v.clone() for k, v in m_.items()} for m_ in masks])
+    tr.rng_parity = False
+    torch.manual_seed(0)
+    a = {k: float(v) for k, v in tr.step(img, lab).items()}
+    for k in SCALARS:
+        assert np.isfinite(a[k]), k
+    assert abs(a["loss"] - (a["loss_cls"] + a["loss_er"] + a["loss_ecr"] + a["loss_nce"])) <= 1e-5 * max(1.0, abs(a["loss"]))
+    assert abs(a["loss_nce"] - (a["loss_intra_nce"] + a["loss_cross_nce"] + a["loss_cross_nce2"])) <= 1e-5
+    assert a["loss_er"] >= 0 and a["loss_ecr"] >= 0
+    eng = model._engine
+    gflat = eng.flat_g.clone()
+    assert torch.isfinite(gflat).all() and float(gflat.abs().max()) > 0
+    for name, (off, cnt) in eng.offsets.items():
+        assert float(gflat[off:off + cnt].abs().max()) > 0, name
+    assert model.conv1a.weight.grad is None and model.b2.conv_branch2a.weight.grad is None
+    model.set_dropout_masks([{k: v.clone() for k, v in m_.items()} for m_ in masks])
+    torch.manual_seed(0)
+    b = {k: float(v) for k, v in tr.step(img, lab).items()}        # lr = 0: same weights, same inputs, same random keys
+    for k in ("loss_cls", "loss_er", "loss_ecr", "loss_cross_nce", "loss_cross_nce2"):
+        assert abs(a[k] - b[k]) <= 2e-6 * max(1.0, abs(a[k])), (k, a[k], b[k])
+    w0 = eng.flat_w.clone()
+    for g_ in opt.param_groups:
+        g_["lr"] = 1e-3
+    opt._PolyOptimizer__initial_lr = [1e-3 for _ in opt.param_groups]
+    tr.step(img, lab)
+    assert float((eng.flat_w - w0).abs().max()) > 0
