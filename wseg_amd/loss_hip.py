@@ -134,6 +134,18 @@ def _merge_prototypes(v, gathered, view_idx, world):
     L.proto_merge(base, base[21 * K:], base[21 * K * 129:].view(torch.int32), v.protos, world, K, 2 * _CAND_L)
 
 
+def _random_keys(P, rank, view_idx, dev):
+    """Per-pixel random keys of the hard-pixel sampling (the 'random half' = the smallest keys of a class).  Normally
+    torch.rand; WSEG_INTRA_KEY_SEED=<int> makes them a fixed function of the GLOBAL pixel index, so that a data-parallel run
+    and a single-process run over the same global batch pick the same pixels (tests/test_gpu_ddp_equivalence.py)."""
+    seed = os.environ.get("WSEG_INTRA_KEY_SEED")
+    if seed is None:
+        return torch.rand(P, device=dev)
+    g = torch.arange(rank * P, (rank + 1) * P, device=dev, dtype=torch.int64)
+    h = (g * 2654435761 + int(seed) * 40503 + view_idx * 97) % 16777213
+    return (h * 48271 % 16777213).float() / 16777213.0
+
+
 def _rand_flags(y_dev, rng, P):
     """RNG-parity mode: the reference's host draws (contrast_train.py:291/:316), as per-pixel flags."""
     y = y_dev.cpu()
@@ -225,7 +237,7 @@ def step(model, img1, img2, label20, bg_threshold=0.20, rng=None, rng_parity=Fal
         rank = dist.get_rank() if world > 1 else 0
         rec = _f32(2, 3, P, dev=dev)
         for vi, v in enumerate(views):
-            L.intra_pack(v.y, v.S_own, torch.rand(P, device=dev), rec[vi], P)
+            L.intra_pack(v.y, v.S_own, _random_keys(P, rank, vi, dev), rec[vi], P)
         grec = rec
         if world > 1:
             grec = _f32(world, 2, 3, P, dev=dev)
