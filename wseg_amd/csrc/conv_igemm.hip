@@ -169,6 +169,116 @@ __device__ __forceinline__ void epilogue_image(const wseg_conv_desc& d, int M, c
   }
 }
 
+// ---- wave-local epilogue of the phase-pipelined kernels: every wave turns its own (NI*16) x 64 accumulator tile into
+// 8-channel vectors through a private 16-row LDS scratch (4.25 KiB), NI steps, NO workgroup barrier: the waves drift apart, so
+// one wave's global-load latency (residual / mask / dropout operands, 16 B per lane) overlaps with the other waves' LDS and
+// store work.  (A block-wide LDS image needed 8 barriers and 8 serialised load round trips per 256x256 tile.)  Stores are full
+// 128-B lines: 8 lanes x 16 B per output row.  mw0 = first row of the wave's tile, col0 = its first column inside the
+// column tile n0.  The caller has made sure (barrier) that no wave still reads the pipeline buffers.
+template <int EPI, int NI>
+__device__ __forceinline__ void wave_local_epilogue(const Args& a, char* smem, int wid, int lane, int mw0, int col0, int n0,
+                                                    const f32x4 (&acc)[NI][4]) {
+  constexpr int DT = WSEG_BF16;
+  const wseg_conv_desc& d = a.d;
+  const int frow = lane & 15, fk = lane >> 4;
+  constexpr int WLD = 64 + 4;                      // scratch row stride (floats): conflict-free for both access patterns
+  float* wimg = reinterpret_cast<float*>(smem) + wid * (16 * WLD);
+  const int vr = lane >> 3, vg = lane & 7;         // this lane's vectors: rows vr and vr + 8 of the step, column group vg
+  const int oc_raw = n0 + col0 + vg * 8;
+  const bool col_ok = oc_raw < d.OC;
+  const int oc = col_ok ? oc_raw : 0;
+  float sc[8], sh[8];
+  epilogue_coeffs(d, n0, col0 + vg * 8, sc, sh);
+  const bool has_pre = d.r_pre != nullptr, has_post = d.r_post != nullptr, has_mask = EPI == 1 && d.mask != nullptr;
+  const bool has_drop = EPI != 2 && d.drop != nullptr;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    // operands of this step's two vectors first (their latency overlaps the scratch round trip)
+    size_t mrow[2]; bool ok[2];
+    float rpre[2][8], rpost[2][8], mk[2][8], dr[2][8];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int m = mw0 + i * 16 + vr + 8 * t;
+      ok[t] = col_ok && m < a.M;
+      mrow[t] = ok[t] ? (a.perm ? (size_t)perm_decode(a, m).true_row : (size_t)m) : 0;
+    }
+    if (has_pre) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) load8<DT>(d.r_pre, mrow[t] * d.ld_rpre + oc, rpre[t]);
+    }
+    if (has_post) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) load8<DT>(d.r_post, mrow[t] * d.ld_rpost + oc, rpost[t]);
+    }
+    if (has_mask) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) load8<DT>(d.mask, mrow[t] * d.ld_mask + oc, mk[t]);
+    }
+    if (has_drop) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) load8<WSEG_F32>(d.drop, (size_t)wseg_decode_row(d, (int)mrow[t]).n_glob * d.OC + oc, dr[t]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) wimg[(fk * 4 + e) * WLD + j * 16 + frow] = acc[i][j][e];   // C/D: col = lane&15, row = (lane>>4)*4 + reg
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-local: the scratch is written and read by this wave only
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float v[8];
+      {
+        const f32x4 p0 = *reinterpret_cast<const f32x4*>(&wimg[(vr + 8 * t) * WLD + vg * 8]);
+        const f32x4 p1 = *reinterpret_cast<const f32x4*>(&wimg[(vr + 8 * t) * WLD + vg * 8 + 4]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = p0[e]; v[4 + e] = p1[e]; }
+      }
+      const size_t m = mrow[t];
+      if (has_pre) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += rpre[t][e];
+      }
+      if constexpr (EPI == 0) {
+        if (has_post) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += rpost[t][e];
+        }
+        if (d.relu_lt > 0) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) if (oc + e < d.relu_lt) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (d.out != nullptr && ok[t]) store8<DT>(d.out, m * d.ld_out + oc, v);
+        if (d.out2 != nullptr) {
+          float o2[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float x = v[e] * sc[e] + sh[e];
+            if (d.relu_out2) x = fmaxf(x, 0.f);
+            if (has_drop) x *= dr[t][e];
+            o2[e] = x;
+          }
+          if (ok[t]) store8<DT>(d.out2, m * d.ld_out2 + oc, o2);
+        }
+      } else if constexpr (EPI == 1) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float x = v[e] * sc[e];
+          if (has_drop) x *= dr[t][e];
+          if (has_mask) x = mk[t][e] > 0.f ? x : 0.f;
+          if (has_post) x += rpost[t][e];
+          o[e] = x;
+        }
+        if (ok[t]) store8<DT>(d.out, m * d.ld_out + oc, o);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        if (ok[t]) store8<DT>(d.out, m * d.ld_out + oc, v);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // scratch reads done before the next step overwrites it
+  }
+}
+
 // BM = 128 (default) or 64 (few output pixels: twice the workgroups for the same work)
 template <int DT, int EPI, int BM>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const Args a) {
@@ -589,108 +699,9 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const Args a) {
   }
 #undef MFMA_Q
 
-  // ---- epilogue, WAVE-LOCAL: every wave turns its own 128 x 64 accumulator tile into 8-channel vectors through a private
-  // 16-row LDS scratch (4.25 KiB), 8 steps, no workgroup barrier: the waves drift apart, so one wave's global-load latency
-  // (residual / mask / dropout operands, 16 B per lane) overlaps with the other waves' LDS and store work.  (The previous
-  // block-wide image needed 8 barriers and 8 serialised load round trips per tile: ~10 us of a 40 us tile on the 3x3 512
-  // layers, half the tile time on the 1x1 layers.)  Stores are full 128-B lines: 8 lanes x 16 B per output row.
+  // ---- epilogue, wave-local (see wave_local_epilogue)
   __syncthreads();                                 // every wave is done with the pipeline buffers
-  constexpr int WLD = 64 + 4;                      // scratch row stride (floats): conflict-free for both access patterns
-  float* wimg = reinterpret_cast<float*>(smem) + wid * (16 * WLD);
-  const int vr = lane >> 3, vg = lane & 7;         // this lane's vectors: rows vr and vr + 8 of the step, column group vg
-  const int oc_raw = n0 + wc * 64 + vg * 8;
-  const bool col_ok = oc_raw < d.OC;
-  const int oc = col_ok ? oc_raw : 0;
-  float sc[8], sh[8];
-  epilogue_coeffs(d, n0, wc * 64 + vg * 8, sc, sh);
-  const bool has_pre = d.r_pre != nullptr, has_post = d.r_post != nullptr, has_mask = EPI == 1 && d.mask != nullptr;
-  const bool has_drop = EPI != 2 && d.drop != nullptr;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    // operands of this step's two vectors first (their latency overlaps the scratch round trip)
-    size_t mrow[2]; bool ok[2];
-    float rpre[2][8], rpost[2][8], mk[2][8], dr[2][8];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int m = m0 + wr * 128 + i * 16 + vr + 8 * t;
-      ok[t] = col_ok && m < a.M;
-      mrow[t] = ok[t] ? (a.perm ? (size_t)perm_decode(a, m).true_row : (size_t)m) : 0;
-    }
-    if (has_pre) {
-#pragma unroll
-      for (int t = 0; t < 2; ++t) load8<DT>(d.r_pre, mrow[t] * d.ld_rpre + oc, rpre[t]);
-    }
-    if (has_post) {
-#pragma unroll
-      for (int t = 0; t < 2; ++t) load8<DT>(d.r_post, mrow[t] * d.ld_rpost + oc, rpost[t]);
-    }
-    if (has_mask) {
-#pragma unroll
-      for (int t = 0; t < 2; ++t) load8<DT>(d.mask, mrow[t] * d.ld_mask + oc, mk[t]);
-    }
-    if (has_drop) {
-#pragma unroll
-      for (int t = 0; t < 2; ++t) load8<WSEG_F32>(d.drop, (size_t)wseg_decode_row(d, (int)mrow[t]).n_glob * d.OC + oc, dr[t]);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) wimg[(fk * 4 + e) * WLD + j * 16 + frow] = acc[i][j][e];   // C/D: col = lane&15, row = (lane>>4)*4 + reg
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-local: the scratch is written and read by this wave only
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      float v[8];
-      {
-        const f32x4 p0 = *reinterpret_cast<const f32x4*>(&wimg[(vr + 8 * t) * WLD + vg * 8]);
-        const f32x4 p1 = *reinterpret_cast<const f32x4*>(&wimg[(vr + 8 * t) * WLD + vg * 8 + 4]);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] = p0[e]; v[4 + e] = p1[e]; }
-      }
-      const size_t m = mrow[t];
-      if (has_pre) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += rpre[t][e];
-      }
-      if constexpr (EPI == 0) {
-        if (has_post) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += rpost[t][e];
-        }
-        if (d.relu_lt > 0) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) if (oc + e < d.relu_lt) v[e] = fmaxf(v[e], 0.f);
-        }
-        if (d.out != nullptr && ok[t]) store8<DT>(d.out, m * d.ld_out + oc, v);
-        if (d.out2 != nullptr) {
-          float o2[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            float x = v[e] * sc[e] + sh[e];
-            if (d.relu_out2) x = fmaxf(x, 0.f);
-            if (has_drop) x *= dr[t][e];
-            o2[e] = x;
-          }
-          if (ok[t]) store8<DT>(d.out2, m * d.ld_out2 + oc, o2);
-        }
-      } else if constexpr (EPI == 1) {
-        float o[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float x = v[e] * sc[e];
-          if (has_drop) x *= dr[t][e];
-          if (has_mask) x = mk[t][e] > 0.f ? x : 0.f;
-          if (has_post) x += rpost[t][e];
-          o[e] = x;
-        }
-        if (ok[t]) store8<DT>(d.out, m * d.ld_out + oc, o);
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-        if (ok[t]) store8<DT>(d.out, m * d.ld_out + oc, v);
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // scratch reads done before the next step overwrites it
-  }
+  wave_local_epilogue<EPI, 8>(a, smem, wid, lane, m0 + wr * 128, wc * 64, n0, acc);
 }
 
 
@@ -815,6 +826,8 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256x128_kernel(const Args a)
     __builtin_amdgcn_s_setprio(0);                                                                           \
   } while (0)
 
+  // (lock-step: with only 16 MFMAs per slot the ping-pong variant of this kernel measured 16 % SLOWER — 590 vs 703 TF/s on the
+  //  128->128 3x3 224x224 layers — the extra barriers cost more than the hidden read latency)
   for (int u = 0; u < nt; ++u) {
     const int b = u & 1;
     const char* aH = smem + b * TILE2N + (wr >> 1) * HALF256;
@@ -838,27 +851,8 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256x128_kernel(const Args a)
   }
 #undef MFMA_H
 
-  // ---- epilogue: 2 passes of 128 rows
-  float* img = reinterpret_cast<float*>(smem);
-  float sc[8], sh[8];
-  epilogue_coeffs(d, n0, (tid & 15) * 8, sc, sh);
-#pragma unroll
-  for (int ps = 0; ps < 2; ++ps) {
-    if ((wr >> 1) == ps) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int row = (wr & 1) * 64 + i * 16 + fk * 4;
-          const int col = wc * 64 + j * 16 + frow;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) img[(row + e) * EPI_LD2N + col] = acc[i][j][e];
-        }
-    }
-    __syncthreads();
-    epilogue_image<DT, EPI, 128, 128, EPI_LD2N, 512>(d, a.M, img, m0 + ps * 128, n0, tid, sc, sh);
-    __syncthreads();
-  }
+  __syncthreads();                                 // every wave is done with the pipeline buffers
+  wave_local_epilogue<EPI, 4>(a, smem, wid, lane, m0 + wr * 64, wc * 64, n0, acc);
 }
 
 }  // namespace
