@@ -706,8 +706,8 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const Args a) {
 
 
 // ---- 256(M) x 128(N) bf16 phase-pipelined variant: layers with OC = 128 (the frozen 224x224 prefix) and narrow tails.
-// 8 waves as 4(M) x 2(N), wave tile 64 x 64 = 4 x 4 accumulators; LDS = 2 K-tiles x {A0, A1, B} slots of
-// [128 rows][128 B] = 16 KiB each (96 KiB).  A K-tile is 2 phases of 16 MFMAs (32 rows x 64 cols of the wave tile each;
+// 8 waves as 4(M) x 2(N), wave tile 64 x 64 = 4 x 4 accumulators; LDS = 3 K-tiles x {A0, A1, B} slots of
+// [128 rows][128 B] = 16 KiB each (144 KiB).  A K-tile is 2 phases of 16 MFMAs (32 rows x 64 cols of the wave tile each;
 // the B fragments of phase A are kept in registers for phase B):
 //     pA(u): A0(u+1), A1(u+1)      pB(u): B(u+2), counted s_waitcnt vmcnt(2)
 // 85 FLOP per filled byte (the 128^2 kernel: 64) and one barrier per 16 MFMAs, as in the 256^2 kernel.
@@ -716,7 +716,7 @@ constexpr int TILE2N = 3 * HALF256, EPI_LD2N = 128 + 4;
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void conv_igemm256x128_kernel(const Args a) {
   constexpr int DT = WSEG_BF16, ES = 2, CH = 8;
-  __shared__ __attribute__((aligned(16))) char smem[2 * TILE2N];
+  __shared__ __attribute__((aligned(16))) char smem[3 * TILE2N];   // THREE K-tile buffers (144 KiB): see the loop
   const wseg_conv_desc& d = a.d;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -730,15 +730,24 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256x128_kernel(const Args a)
   const char* IN = reinterpret_cast<const char*>(d.in);
   const char* Wp = reinterpret_cast<const char*>(d.w);
 
-  // staging: thread -> rows r0 + 64*j (j = 0..3) of the A tile, rows r0, r0 + 64 of the B tile (see the 256^2 kernel)
+  // staging: thread -> rows r0 + 64*j (j = 0..3) of the A tile, rows r0, r0 + 64 of the B tile (see the 256^2 kernel).
+  // These narrow layers change tap every 1-4 K-tiles (IC = 64..256) with only 32 MFMAs per wave per K-tile, so the per-tap
+  // address work must be small or the loop is VALU-issue bound: the gather address is  row pointer (per row, computed once,
+  // possibly outside the tensor) + tap offset (two scalars per tap, one per row segment), and the validity test is two
+  // unsigned compares on (iy0 + dy, ix0 + dx) — branch-free, ~16 vector instructions per row.  (fast_tap: every case except
+  // the stride-2 data gradient, which keeps the generic divisibility logic.)
   const int r0 = tid >> 3, pch = tid & 7;
   const int lc = pch ^ ((r0 >> 1) & 7);
   const char* zsrc = zero + pch * 16;
   const char* INl = IN + lc * 16;
+  const bool fast_tap = d.mode == 0 || d.stride == 1;
   int a_base[4], a_yx[4];
+  const char* rowptr[4];
+  int a_iy0[4], a_ix0[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int m = m0 + r0 + 64 * j;
+    rowptr[j] = zsrc; a_iy0[j] = -0x2000; a_ix0[j] = -0x2000;       // (rows beyond M: never in bounds)
     if (m < a.M) {
       const wseg_rowgeo rg = wseg_decode_row(d, m);
       int iy0, ix0;
@@ -746,6 +755,8 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256x128_kernel(const Args a)
       else             { iy0 = rg.oy + d.pad;            ix0 = rg.ox + d.pad; }
       a_base[j] = (int)rg.in_base;
       a_yx[j] = (rg.n_glob >= d.N ? (int)0x80000000 : 0) | ((iy0 + 0x2000) << 16) | (ix0 + 0x2000);
+      a_iy0[j] = iy0; a_ix0[j] = ix0;
+      rowptr[j] = INl + ((long)rg.in_base + (long)iy0 * rg.IW + ix0) * d.ld_in * ES;
     } else {
       a_base[j] = -1; a_yx[j] = (0x2000 << 16) | 0x2000;
     }
@@ -757,6 +768,20 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256x128_kernel(const Args a)
   auto set_tap = [&](int tap) {
     const int ky = tap / d.KW, kx = tap - ky * d.KW;
     a_live = 0;
+    if (fast_tap) {
+      const int dyt = d.mode == 0 ? ky * d.dil : -ky * d.dil, dxt = d.mode == 0 ? kx * d.dil : -kx * d.dil;   // (uniform)
+      const long off1 = ((long)dyt * d.IW + dxt) * d.ld_in * ES, off2 = ((long)dyt * d.IW2 + dxt) * d.ld_in * ES;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool s2 = a_yx[j] < 0;
+        const unsigned H = s2 ? d.IH2 : d.IH, W = s2 ? d.IW2 : d.IW;
+        const bool ok = (unsigned)(a_iy0[j] + dyt) < H && (unsigned)(a_ix0[j] + dxt) < W;
+        const char* p = rowptr[j] + (s2 ? off2 : off1);
+        aptr[j] = ok ? p : zsrc;
+        a_live |= ok ? 1u << j : 0u;
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int iy0 = ((a_yx[j] >> 16) & 0x7FFF) - 0x2000, ix0 = (a_yx[j] & 0xFFFF) - 0x2000;
@@ -802,9 +827,14 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256x128_kernel(const Args a)
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nt = a.taps * a.cpt;
+  // Three-buffer ring: A runs 2 tiles ahead, B 3 (its slot is free after phase A) — ~110 KiB of LDS-DMA in flight per CU.
+  // These OC = 128 layers stream their pixels from HBM (224x224 maps, little reuse per row), where a CU's DMA rate is set
+  // by latency x bytes in flight; with two buffers (72 KiB in flight) the kernel only matched the 128^2 kernel.
   set_tap(0);
   issue_a(0); issue_b(0);
-  if (nt > 1) { issue_b(1); asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+  if (nt > 1) { issue_a(1); issue_b(1); }
+  if (nt > 2) { issue_b(2); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+  else if (nt > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
@@ -828,26 +858,29 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256x128_kernel(const Args a)
 
   // (lock-step: with only 16 MFMAs per slot the ping-pong variant of this kernel measured 16 % SLOWER — 590 vs 703 TF/s on the
   //  128->128 3x3 224x224 layers — the extra barriers cost more than the hidden read latency)
+  int b = 0, b2 = 2;                               // buffers of tile u and of tile u+2
   for (int u = 0; u < nt; ++u) {
-    const int b = u & 1;
     const char* aH = smem + b * TILE2N + (wr >> 1) * HALF256;
     const char* bH = smem + b * TILE2N + 2 * HALF256;
-    // ---- pA: rows 0-31 of the wave tile
+    // ---- pA: rows 0-31 of the wave tile; A(u+2) refills the buffer tile u-1 has left
     ldA(aH, 0);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         bf[ks][j] = *reinterpret_cast<const bf16x8*>(bH + (wc * 64 + j * 16 + frow) * 128 + (((ks * 4 + fk) ^ sw) << 4));
-    if (u + 1 < nt) issue_a(b ^ 1);
+    if (u + 2 < nt) issue_a(b2);
     MFMA_H(0);
     __builtin_amdgcn_s_barrier();
-    // ---- pB: rows 32-63; the counted wait publishes tile u+1 (only B(u+2) may stay in flight)
+    // ---- pB: rows 32-63; B(u+3) refills this tile's own B slot (read in pA); the counted wait publishes tile u+1:
+    //      younger operations that may stay in flight = B(u+2), A(u+2) (2 + 4) and B(u+3) (2)
     ldA(aH, 1);
-    if (u + 2 < nt) { issue_b(b); asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+    if (u + 3 < nt) { issue_b(b); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+    else if (u + 2 < nt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     MFMA_H(1);
     __builtin_amdgcn_s_barrier();
+    b2 = b; b = b == 2 ? 0 : b + 1;                // (u+1) % 3 ; (u+3) % 3 == u % 3
   }
 #undef MFMA_H
 
