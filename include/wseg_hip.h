@@ -61,7 +61,8 @@ typedef struct wseg_conv_desc {
   int32_t relu_out2;   /* 1: out2 gets the ReLU (default); 0: affine only */
   int32_t relu_lt;     /* epi 0: ReLU on `out` channels < relu_lt (fused head: f_proj | cam); 0 = none */
   int32_t bm_hint;     /* 0 = library chooses the tile (64 / 128 pixel rows x 128 channels, or the 256 x 256 phase-pipelined
-                          bf16 kernel for large layers with OC % 256 == 0); 64 / 128 / 256 = force */
+                          bf16 kernel for large layers with OC % 256 == 0, or the 512 x 128 one for OC = 128 layers with many pixels);
+                          64 / 128 / 256 = force; 257 / 258 / 259 = test hooks (row split, 256 x 128 tile, 512 x 128 tile) */
   /* optional SECOND row segment (the 128x128 view batched behind the 448x448 view in one launch): rows
    * [0, N*OH*OW) use (IH,IW,OH,OW); rows beyond use (IH2,IW2,OH2,OW2), same N, their input pixels follow the
    * first segment's N*IH*IW rows; drop then has 2N rows.  OH2 == 0: single segment. */

@@ -888,6 +888,152 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256x128_kernel(const Args a)
   wave_local_epilogue<EPI, 4>(a, smem, wid, lane, m0 + wr * 64, wc * 64, n0, acc);
 }
 
+
+// ---- 512(M) x 128(N) bf16 phase-pipelined variant for OC = 128 layers (the frozen 224x224 prefix) -----------------------
+// Every kernel with a 128-wide column tile so far gave those layers ~680 TF/s whatever its pipeline depth, operand source
+// or address work; what they share is 32 MFMAs per wave per K-tile — half of the 256^2 kernel's — against the same fixed
+// per-K-tile costs (barriers, fragment-read latency, DMA issue).  This variant keeps the 256^2 kernel's wave tile (128 x 64,
+// 64 MFMAs per K-tile, 2-phase ping-pong) by stacking FOUR 128-row A half-tiles: 8 waves as 4(M) x 2(N), LDS = 2 K-tiles x
+// {A0..A3, B} x 16 KiB = 160 KiB (all of it).  Gather addresses: row pointer + per-tap scalar offset, branch-free validity
+// (fast taps only: forward, or stride-1 data gradient).
+constexpr int TILE5 = 5 * HALF256;
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void conv_igemm512x128_kernel(const Args a) {
+  constexpr int ES = 2, CH = 8;
+  __shared__ __attribute__((aligned(16))) char smem[2 * TILE5];
+  const wseg_conv_desc& d = a.d;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tile = xcd_remap(blockIdx.x, a.nwg);
+  const int tm = tile / a.ntn, tn = tile - tm * a.ntn;
+  const int m0 = a.row0 + tm * 512, n0 = tn * 128;
+  const int wr = wid >> 1, wc = wid & 1;
+  const int frow = lane & 15, fk = lane >> 4, sw = (lane >> 1) & 7;
+
+  const char* zero = reinterpret_cast<const char*>(g_wseg_zero_page);
+  const char* IN = reinterpret_cast<const char*>(d.in);
+  const char* Wp = reinterpret_cast<const char*>(d.w);
+
+  // staging: thread -> rows r0 + 64*j (j = 0..7) of the A tile (slot j>>1), rows r0, r0 + 64 of the B tile
+  const int r0 = tid >> 3, pch = tid & 7;
+  const int lc = pch ^ ((r0 >> 1) & 7);
+  const char* zsrc = zero + pch * 16;
+  const char* INl = IN + lc * 16;
+  const char* rowptr[8];                           // pixel (iy0, ix0) of the row's image (possibly outside the tensor)
+  int a_yx[8];                                     // packed (iy0 + 0x2000) << 16 | (ix0 + 0x2000); rows beyond M: never in bounds
+  unsigned segmask = 0;                            // bit j: row j lies in the second row segment
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int m = m0 + r0 + 64 * j;
+    rowptr[j] = zsrc; a_yx[j] = 0;
+    if (m < a.M) {
+      const wseg_rowgeo rg = wseg_decode_row(d, m);
+      int iy0, ix0;
+      if (d.mode == 0) { iy0 = rg.oy * d.stride - d.pad; ix0 = rg.ox * d.stride - d.pad; }
+      else             { iy0 = rg.oy + d.pad;            ix0 = rg.ox + d.pad; }
+      a_yx[j] = ((iy0 + 0x2000) << 16) | (ix0 + 0x2000);
+      segmask |= rg.n_glob >= d.N ? 1u << j : 0u;
+      rowptr[j] = INl + ((long)rg.in_base + (long)iy0 * rg.IW + ix0) * d.ld_in * ES;
+    }
+  }
+  unsigned a_ok = 0;                               // bit j: row j is inside the image for the current tap
+  long koff1 = 0, koff2 = 0;                       // tap offset + K offset inside the tap (bytes), per row segment
+  const char* bptr = Wp + ((size_t)(n0 + r0) * a.taps * d.IC + (size_t)lc * CH) * ES;   // OC % 128 == 0 (host-checked)
+  const int brs = 64 * a.taps * d.IC * ES;
+  auto set_tap = [&](int tap) {
+    const int ky = tap / d.KW, kx = tap - ky * d.KW;
+    const int dyt = d.mode == 0 ? ky * d.dil : -ky * d.dil, dxt = d.mode == 0 ? kx * d.dil : -kx * d.dil;   // (uniform)
+    koff1 = ((long)dyt * d.IW + dxt) * d.ld_in * ES; koff2 = ((long)dyt * d.IW2 + dxt) * d.ld_in * ES;
+    a_ok = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const bool s2 = (segmask >> j) & 1u;
+      const unsigned H = s2 ? d.IH2 : d.IH, W = s2 ? d.IW2 : d.IW;
+      const int iy = (a_yx[j] >> 16) - 0x2000 + dyt, ix = (a_yx[j] & 0xFFFF) - 0x2000 + dxt;
+      a_ok |= ((unsigned)iy < H && (unsigned)ix < W) ? 1u << j : 0u;
+    }
+  };
+  int a_tap = 0, a_cc = 0;
+  auto issue_a = [&](int buf) {                    // the NEXT A tile (8 pieces), then advance
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const char* p = rowptr[j] + (((segmask >> j) & 1u) ? koff2 : koff1);
+      p = ((a_ok >> j) & 1u) ? p : zsrc;
+      glds16(p, smem + buf * TILE5 + (j >> 1) * HALF256 + (j & 1) * 8192 + wid * 1024);
+    }
+    koff1 += 128; koff2 += 128;
+    if (++a_cc == a.cpt) { a_cc = 0; if (++a_tap < a.taps) set_tap(a_tap); }
+  };
+  auto issue_b = [&](int buf) {                    // the NEXT B tile (2 pieces), then advance
+    char* dst = smem + buf * TILE5 + 4 * HALF256 + wid * 1024;
+    glds16(bptr, dst);
+    glds16(bptr + brs, dst + 8192);
+    bptr += 128;
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nt = a.taps * a.cpt;
+  set_tap(0);
+  issue_a(0); issue_b(0);
+  if (nt > 1) { issue_b(1); asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  bf16x8 af[2][4], bf[2][4];
+  auto ldA = [&](const char* aH, int ha) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        af[ks][i] = *reinterpret_cast<const bf16x8*>(aH + (ha * 64 + i * 16 + frow) * 128 + (((ks * 4 + fk) ^ sw) << 4));
+  };
+#define MFMA_H5(HA)                                                                                          \
+  do {                                                                                                       \
+    __builtin_amdgcn_s_setprio(1);                                                                           \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                         \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                          \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                        \
+          acc[(HA) * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][i], bf[ks][j], acc[(HA) * 4 + i][j], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                           \
+  } while (0)
+
+  // 2-phase ping-pong (see conv_igemm256_kernel): waves 4-7 (wr >= 2) run one slot behind waves 0-3
+  const int grp = wr >> 1;
+  if (grp == 1) __builtin_amdgcn_s_barrier();
+  for (int u = 0; u < nt; ++u) {
+    const int b = u & 1;
+    const char* aH = smem + b * TILE5 + wr * HALF256;
+    const char* bH = smem + b * TILE5 + 4 * HALF256;
+    ldA(aH, 0);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        bf[ks][j] = *reinterpret_cast<const bf16x8*>(bH + (wc * 64 + j * 16 + frow) * 128 + (((ks * 4 + fk) ^ sw) << 4));
+    if (u + 1 < nt) issue_a(b ^ 1);
+    __builtin_amdgcn_s_barrier();
+    MFMA_H5(0);
+    __builtin_amdgcn_s_barrier();
+    ldA(aH, 1);
+    if (u + 2 < nt) { issue_b(b); asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    MFMA_H5(1);
+    __builtin_amdgcn_s_barrier();
+  }
+  if (grp == 0) __builtin_amdgcn_s_barrier();
+#undef MFMA_H5
+
+  __syncthreads();                                 // every wave is done with the pipeline buffers
+  wave_local_epilogue<EPI, 8>(a, smem, wid, lane, m0 + wr * 128, wc * 64, n0, acc);
+}
+
 }  // namespace
 
 extern "C" int wseg_conv_igemm(const wseg_conv_desc* d, void* stream) {
@@ -932,7 +1078,7 @@ extern "C" int wseg_conv_igemm(const wseg_conv_desc* d, void* stream) {
   a.row0 = 0;
   // 256x256 phase-pipelined tiles (bf16, OC >= 256): chosen when the (1 workgroup / CU) rounds are full enough
   bool big = false;
-  if (d->dtype == WSEG_BF16 && d->OC % 256 == 0 && d->bm_hint != 64 && d->bm_hint != 128 && d->bm_hint != 258 && d->bm_hint >= 0) {   // (257: test hook, forces the row split)
+  if (d->dtype == WSEG_BF16 && d->OC % 256 == 0 && d->bm_hint != 64 && d->bm_hint != 128 && d->bm_hint != 258 && d->bm_hint != 259 && d->bm_hint >= 0) {   // (257: test hook, forces the row split)
     const long t256 = ((M + 255) / 256) * ((d->OC + 255) / 256);
     const long rounds = (t256 + 255) / 256;
     static const int auto256 = getenv("WSEG_CONV256") ? atoi(getenv("WSEG_CONV256")) : 1;   // (0: A/B switch)
@@ -947,6 +1093,21 @@ extern "C" int wseg_conv_igemm(const wseg_conv_desc* d, void* stream) {
   // the frozen 224x224 prefix (128->128 3x3, K = 1152): 703 vs 700 TF/s for the 128^2 kernel — those layers are bound by
   // their epilogue (18 K-tiles per tile), which two resident workgroups per CU overlap and one cannot; off by default.
   static const int auto2n = getenv("WSEG_CONV256X128") ? atoi(getenv("WSEG_CONV256X128")) : 0;
+  // 512 x 128 phase-pipelined tiles for OC = 128 layers with many pixels (259 forces it); fast taps only
+  static const int auto512 = getenv("WSEG_CONV512") ? atoi(getenv("WSEG_CONV512")) : 1;   // (0: A/B switch; measured 649 -> 766 TF/s on 128->128 3x3 224^2)
+  const bool tall = !big && d->dtype == WSEG_BF16 && d->OC % 128 == 0 && (d->mode == 0 || d->stride == 1) &&
+                    (d->bm_hint == 259 || (auto512 && d->bm_hint == 0 && d->OC == 128 && (M + 511) / 512 >= 512));
+  if (tall) {
+    WSEG_CHECK(d->IH <= 8000 && d->IW <= 8000 && d->OH <= 8000 && d->OW <= 8000 && d->pad <= 4096 && d->KH * d->dil <= 4096,
+               "conv_igemm: shape too large for the 512x128-tile kernel");
+    a.ntn = d->OC / 128;
+    a.nwg = (int)(((M + 511) / 512) * a.ntn);
+    if (d->epi == 0) hipLaunchKernelGGL(conv_igemm512x128_kernel<0>, dim3(a.nwg), dim3(512), 0, s, a);
+    else if (d->epi == 1) hipLaunchKernelGGL(conv_igemm512x128_kernel<1>, dim3(a.nwg), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL(conv_igemm512x128_kernel<2>, dim3(a.nwg), dim3(512), 0, s, a);
+    WSEG_LAUNCH_CHECK();
+    return 0;
+  }
   const bool mid = !big && d->dtype == WSEG_BF16 && d->OC % 128 == 0 &&
                    (d->bm_hint == 258 || (auto2n && d->bm_hint == 0 && d->OC == 128 && (M + 255) / 256 >= 512));
   if (mid) {
