@@ -206,6 +206,27 @@ def step(model, img1, img2, label20, bg_threshold=0.20, rng=None, rng_parity=Fal
         dist.all_gather_into_tensor(gathered.view(world * 2, _CAND_L), cand)
     for vi, v in enumerate(views):
         _merge_prototypes(v, gathered, vi, world)
+    # ---- pixel-to-prototype similarities + hard-pixel records on a side stream, concurrently with the ER / ECR chain below
+    # (the radix-select kernel is also the faster one on a single rank — 47 vs 118 us; the sort-based kernel remains the
+    #  RNG-parity path, which replays the reference's host random stream)
+    global_intra = world > 1 or (not rng_parity and os.environ.get("WSEG_INTRA_GLOBAL", "1") == "1")
+    rank = dist.get_rank() if world > 1 else 0
+    cst = side[1]
+    cst.wait_stream(main)
+    with torch.cuda.stream(cst):
+        for v, o in ((v1, v2), (v2, v1)):
+            v.fn, v.nrm = _f32(P, 128, dev=dev), _f32(P, dev=dev)
+            v.S_own, v.S_oth = _f32(P, 21, dev=dev), _f32(P, 21, dev=dev)
+            L.nce_sims(v.F, v.protos, o.protos, v.fn, v.nrm, v.S_own, v.S_oth, P)
+        if global_intra:
+            # Hard-pixel sampling over the GLOBAL batch (the reference samples on the gathered batch): one
+            # all-gather of {label, own-class similarity, random key} per pixel (96 KB per rank for both views); every rank
+            # then finds the same global per-class order statistics and keeps the weights of its own pixels, scaled by
+            # `world` because the gradient all-reduce averages.
+            rec = _f32(2, 3, P, dev=dev)
+            for vi, v in enumerate(views):
+                L.intra_pack(v.y, v.S_own, _random_keys(P, rank, vi, dev), rec[vi], P)
+            grec = rec
     # ---- ER + ECR on the 128x128 maps (both directions of the ECR top-k in ONE 2N-row selection)
     npix = 128 * 128
     er_coef = 1.0 / (N * 20 * npix)
@@ -221,28 +242,11 @@ def step(model, img1, img2, label20, bg_threshold=0.20, rng=None, rng_parity=Fal
     Gr = _f32(2 * N, 21, 128, 128, dev=dev)
     L.ecr_backward(dlt, res, Gr, 2 * N, 21 * npix, K_ecr, 1.0 / (N * K_ecr))
     v1.Gr, v2.Gr = Gr[:N], Gr[N:]
-    # ---- pixel-to-prototype contrast at 16x16
-    for v, o in ((v1, v2), (v2, v1)):
-        v.fn, v.nrm = _f32(P, 128, dev=dev), _f32(P, dev=dev)
-        v.S_own, v.S_oth = _f32(P, 21, dev=dev), _f32(P, 21, dev=dev)
-        L.nce_sims(v.F, v.protos, o.protos, v.fn, v.nrm, v.S_own, v.S_oth, P)
-    # (the radix-select kernel is also the faster one on a single rank — 47 vs 118 us; the sort-based kernel remains the
-    #  RNG-parity path, which replays the reference's host random stream)
-    global_intra = world > 1 or (not rng_parity and os.environ.get("WSEG_INTRA_GLOBAL", "1") == "1")
-    if global_intra:
-        # Hard-pixel sampling over the GLOBAL batch (the reference samples on the gathered batch): one
-        # all-gather of {label, own-class similarity, random key} per pixel (96 KB per rank for both views); every rank
-        # then finds the same global per-class order statistics and keeps the weights of its own pixels, scaled by
-        # `world` because the gradient all-reduce averages.
-        rank = dist.get_rank() if world > 1 else 0
-        rec = _f32(2, 3, P, dev=dev)
-        for vi, v in enumerate(views):
-            L.intra_pack(v.y, v.S_own, _random_keys(P, rank, vi, dev), rec[vi], P)
-        grec = rec
-        if world > 1:
-            grec = _f32(world, 2, 3, P, dev=dev)
-            dist.all_gather_into_tensor(grec.view(world * 6, P), rec.view(6, P))
-    elif rng_parity:
+    main.wait_stream(cst)
+    if global_intra and world > 1:                          # (collectives stay on the main stream, in program order)
+        grec = _f32(world, 2, 3, P, dev=dev)
+        dist.all_gather_into_tensor(grec.view(world * 6, P), rec.view(6, P))
+    elif rng_parity and not global_intra:
         for v in views:                                    # view 1 fully before view 2 (RNG order of the reference)
             v.w_intra = _f32(P, dev=dev)
             L.intra_weights(v.y, v.S_own, None, _rand_flags(v.y, rng, P), v.w_intra, P)
