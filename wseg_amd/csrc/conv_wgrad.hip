@@ -34,6 +34,7 @@ struct Args {
   int pix_per_split;
   int nsplit, nwg;
   int simple_adv, q64_1, r64_1, q64_2, r64_2;   // pipe kernel: 64 pixels = q*OW + r per row segment (simple_adv: one image wrap at most)
+  int wave_epi;      // pipe kernel: 1 = wave-local atomic epilogue (WSEG_WGRAD_EPI)
   int stagger;       // 1 = ping-pong schedule of the pipe kernel (WSEG_WGRAD_STAGGER; off: its read slots — 24/8/16/0 transposed
                      //     reads + pixel addressing — are longer and less even than an MFMA slot, the stagger then costs time)
   int diag;          // 0 = normal; timing diagnostics (WSEG_WGRAD_DIAG): 1 = no epilogue stores, 2 = plain stores
@@ -601,8 +602,33 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pipe_kernel(const Args a) {
 #undef PACK_B
 #undef WAIT_LDS
 #undef MFMA_Q
-  __syncthreads();
+  __syncthreads();                                 // every wave is done with the pipeline buffers
 
+  if (a.wave_epi) {
+    // Epilogue, wave-local (default; WSEG_WGRAD_EPI=0 = the block-wide image below): every wave adds its own 128(oc) x 64(ic) accumulator tile to dW through
+    // a private 16-row LDS scratch, no workgroup barrier; one atomic wave-instruction = 64 consecutive floats (256 B).
+    constexpr int WLD = 64 + 4;
+    float* wimg = reinterpret_cast<float*>(smem) + wid * (16 * WLD);
+    const size_t row_stride = (size_t)a.taps * d.IC_dw;
+    const int ic = ic0 + wc * 64 + lane;
+    const bool ic_ok = ic < d.IC_dw;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wimg[(fk * 4 + e) * WLD + j * 16 + fcol] = acc[i][j][e];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const int oc_base = oc0 + wr * 128 + i * 16;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int oc = oc_base + r;
+        if (ic_ok && oc < d.OC_dw) atomicAdd(&d.dw[(size_t)oc * row_stride + (size_t)tap * d.IC_dw + ic], wimg[r * WLD + lane]);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    return;
+  }
   float* img = reinterpret_cast<float*>(smem);
   const size_t row_stride = (size_t)a.taps * d.IC_dw;
 #pragma unroll 1
@@ -688,6 +714,8 @@ extern "C" int wseg_conv_wgrad(const wseg_wgrad_desc* d, void* stream) {
   a.simple_adv = (a.q64_1 + 1 <= d->OH) && (d->OH2 == 0 || a.q64_2 + 1 <= d->OH2);
   static const int diag = getenv("WSEG_WGRAD_DIAG") ? atoi(getenv("WSEG_WGRAD_DIAG")) : 0;
   a.diag = diag;
+  static const int wave_epi = getenv("WSEG_WGRAD_EPI") ? atoi(getenv("WSEG_WGRAD_EPI")) : 1;   // (same-box A/B: 12.64 vs 12.73 ms/step)
+  a.wave_epi = wave_epi;
   static const int stagger = getenv("WSEG_WGRAD_STAGGER") ? atoi(getenv("WSEG_WGRAD_STAGGER")) : 2;   // (2 measured best: 14.06 vs 14.85 / 15.9 ms/step) 0/1: 4 phases lock-step / ping-pong (1 measured slower: 17.1 vs 14.8 ms/step); 2/3: 2 phases lock-step / ping-pong
   a.stagger = stagger;
   hipStream_t s = (hipStream_t)stream;
