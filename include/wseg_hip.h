@@ -97,6 +97,8 @@ int wseg_pack_weights(const float* master, void* fwd, void* tr, int OC, int T, i
  * written as [IC][T][OC] in `dtype` at out + off_out[l] (element offsets).  `table` (device, int64) holds per layer
  * {index of its first 32x32 tile, off_in, off_out, OC, T, IC}; total_tiles = sum of ceil(OC/32)*ceil(IC/32)*T. */
 int wseg_pack_transposed_batch(const float* master, void* out, const long* table, int nlayers, long total_tiles, int dtype, void* stream);
+/* the same from the bf16 weight mirror (bf16 -> bf16), `table` counted in 64x64 tiles */
+int wseg_pack_transposed_batch_bf16(const void* mirror, void* out, const long* table, int nlayers, long total_tiles, void* stream);
 /* Dropout2d scales (resnet38d.py:64,68,86,91; resnet38_contrast.py:14,34) from uniforms u in [0,1):
  * out[i] = u[i] >= p ? 1/(1-p) : 0 with p = p0 for i < split_at, p1 after (one launch for all five masks). */
 int wseg_dropout_scale(const float* u, float* out, long total, long split_at, float p0, float p1, void* stream);

@@ -266,3 +266,28 @@ def test_conv256_fwd_dgrad(case):
         L.conv_igemm(_nhwc(dy).to(dev, tdt), wt, dxg, N=N, IH=OH, IW=OW, IC=OC, OH=H, OW=W, OC=IC, KH=k, KW=k, stride=s, dil=d,
                      pad=pad, mode=1, bm_hint=256)
         np.testing.assert_allclose(dxg.float().cpu().numpy(), _nhwc(x.grad).numpy(), **tol)
+
+
+def test_batched_transposed_pack_bf16_matches_f32_source():
+    """The two batched transposed-pack kernels (f32 master -> bf16, and bf16 mirror -> bf16 on 64x64 tiles) agree bit for bit
+    on a table of layers with odd sizes."""
+    from wseg_amd import _lib as L
+    dev = "cuda"
+    layers = [(96, 9, 40), (64, 1, 200), (130, 9, 72), (32, 1, 32)]          # (OC, T, IC)
+    total = sum(o * t * i for o, t, i in layers)
+    master = _rand((total,), 5).to(dev)
+    mirror = master.to(torch.bfloat16)
+    rows32, rows64, t32, t64, off = [], [], 0, 0, 0
+    for (o, t, i) in layers:
+        rows32.append([t32, off, off, o, t, i]); rows64.append([t64, off, off, o, t, i])
+        t32 += ((o + 31) // 32) * ((i + 31) // 32) * t
+        t64 += ((o + 63) // 64) * ((i + 63) // 64) * t
+        off += o * t * i
+    a = torch.zeros(total, device=dev, dtype=torch.bfloat16)
+    b = torch.zeros(total, device=dev, dtype=torch.bfloat16)
+    L.pack_transposed_batch(master, a, torch.tensor(rows32, dtype=torch.int64, device=dev), len(layers), t32, L.BF16)
+    L.pack_transposed_batch_bf16(mirror, b, torch.tensor(rows64, dtype=torch.int64, device=dev), len(layers), t64)
+    assert torch.equal(a, b)
+    o, t, i = layers[0]
+    ref = mirror[:o * t * i].view(o, t, i).permute(2, 1, 0).contiguous().view(-1)
+    assert torch.equal(b[:o * t * i], ref)

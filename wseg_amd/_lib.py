@@ -152,6 +152,11 @@ def pack_transposed_batch(master, out, table, nlayers, total_tiles, dtype):
                                          C.c_long(total_tiles), dtype, C.c_void_p(stream_ptr())), "wseg_pack_transposed_batch")
 
 
+def pack_transposed_batch_bf16(mirror, out, table, nlayers, total_tiles):
+    check(lib.wseg_pack_transposed_batch_bf16(C.c_void_p(_ptr(mirror)), C.c_void_p(_ptr(out)), C.c_void_p(_ptr(table)), nlayers,
+                                              C.c_long(total_tiles), C.c_void_p(stream_ptr())), "wseg_pack_transposed_batch_bf16")
+
+
 def dropout_scale(u, out, split_at, p0, p1):
     check(lib.wseg_dropout_scale(C.c_void_p(_ptr(u)), C.c_void_p(_ptr(out)), C.c_long(u.numel()), C.c_long(split_at),
                                  C.c_float(p0), C.c_float(p1), C.c_void_p(stream_ptr())), "wseg_dropout_scale")

@@ -71,6 +71,33 @@ __global__ void pack_tr_batch_kernel(const float* __restrict__ master, void* __r
   }
 }
 
+// bf16 -> bf16 variant on 64x64 tiles (source = the bf16 weight mirror the fused SGD writes): 128-B row segments on both sides,
+// a third of the f32 version's traffic.  table[l] = {first 64x64 tile, off_in, off_out, OC, T, IC}.
+__global__ __launch_bounds__(256) void pack_tr_batch_bf16_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ out, const long* __restrict__ table, int nlayers) {
+  __shared__ bf16_t tile[64][66];
+  const long bid = blockIdx.x;
+  int lo = 0, hi = nlayers - 1;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (table[mid * 6] <= bid) lo = mid; else hi = mid - 1; }
+  const long* e = table + lo * 6;
+  const int OC = (int)e[3], T = (int)e[4], IC = (int)e[5];
+  const int nti = (IC + 63) / 64, nto = (OC + 63) / 64;
+  long r = bid - e[0];
+  const int ti = (int)(r % nti); r /= nti;
+  const int to = (int)(r % nto); const int t = (int)(r / nto);
+  const bf16_t* w = src + e[1];
+  const int oc0 = to * 64, ic0 = ti * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int rr = ty; rr < 64; rr += 4) {
+    const int oc = oc0 + rr, ic = ic0 + tx;
+    tile[rr][tx] = (oc < OC && ic < IC) ? w[((size_t)oc * T + t) * IC + ic] : (bf16_t)0;
+  }
+  __syncthreads();
+  for (int rr = ty; rr < 64; rr += 4) {
+    const int ic = ic0 + rr, oc = oc0 + tx;
+    if (ic < IC && oc < OC) out[(size_t)e[2] + ((size_t)ic * T + t) * OC + oc] = tile[tx][rr];
+  }
+}
+
 // ---- Dropout2d scales for one step from uniforms: out[i] = u[i] >= p ? 1/(1-p) : 0, p = p0 for i < split_at else p1
 __global__ void dropout_scale_kernel(const float* __restrict__ u, float* __restrict__ out, long total, long split_at, float p0, float p1) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -193,6 +220,13 @@ extern "C" int wseg_pack_transposed_batch(const float* master, void* out, const 
 extern "C" int wseg_dropout_scale(const float* u, float* out, long total, long split_at, float p0, float p1, void* stream) {
   WSEG_CHECK(u && out && total > 0 && p0 >= 0.f && p0 < 1.f && p1 >= 0.f && p1 < 1.f, "dropout_scale: bad arguments");
   hipLaunchKernelGGL(dropout_scale_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, u, out, total, split_at, p0, p1);
+  WSEG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wseg_pack_transposed_batch_bf16(const void* mirror, void* out, const long* table, int nlayers, long total_tiles, void* stream) {
+  WSEG_CHECK(mirror && out && table && nlayers > 0 && total_tiles > 0 && total_tiles < (1L << 31), "pack_transposed_batch_bf16: bad arguments");
+  hipLaunchKernelGGL(pack_tr_batch_bf16_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)mirror, (bf16_t*)out, table, nlayers);
   WSEG_LAUNCH_CHECK();
   return 0;
 }

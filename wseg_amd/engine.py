@@ -195,7 +195,16 @@ class Engine:
                     tiles += ((co + 31) // 32) * ((ci + 31) // 32) * k * k
             self._wt_table = torch.tensor(rows, dtype=torch.int64, device=device)
             self._wt_tiles = tiles
-        L.pack_transposed_batch(self.flat_w, self.flat_wt, self._wt_table, self._wt_table.shape[0], self._wt_tiles, dt)
+            rows64, t64 = [], 0                              # the bf16 -> bf16 variant works on 64x64 tiles
+            for (_t, off_i, off_o, co, T_, ci) in rows:
+                rows64.append([t64, off_i, off_o, co, T_, ci])
+                t64 += ((co + 63) // 64) * ((ci + 63) // 64) * T_
+            self._wt_table64 = torch.tensor(rows64, dtype=torch.int64, device=device)
+            self._wt_tiles64 = t64
+        if dt == L.BF16:                                     # from the bf16 mirror (written by the fused SGD): a third of the traffic
+            L.pack_transposed_batch_bf16(mirror, self.flat_wt, self._wt_table64, self._wt_table64.shape[0], self._wt_tiles64)
+        else:
+            L.pack_transposed_batch(self.flat_w, self.flat_wt, self._wt_table, self._wt_table.shape[0], self._wt_tiles, dt)
         for b in arch.BLOCKS:
             if b[0] in arch.FROZEN_BLOCKS:
                 continue
