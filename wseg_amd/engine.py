@@ -16,7 +16,7 @@ import torch
 from . import arch
 from . import _lib as L
 
-HEAD_LD = 192          # fused head rows: [f_proj 128 | cam 21 | zero pad 43]
+HEAD_LD = int(os.environ.get("WSEG_HEAD_LD", "192"))   # fused head rows: [f_proj 128 | cam 21 | zero pad]  (256: the head GEMMs take the 256-tile kernels)
 FEAT_LD = 256          # PCM feature rows: [f8_3 64 | f8_4 128 | x_s 3 | zero pad 61]
 
 
