@@ -28,6 +28,7 @@ struct Args {
   int ntn;          // column tiles
   int nwg;
   int row0;         // first output row (pixel) of this launch (a launch may cover a row sub-range)
+  int early_b;      // 256-tile kernel: weight DMA of the first two K-tiles issued before the row decode
   int perm;         // 256-tile kernel, stride-2 dgrad: rows are taken in PARITY-CLASS order (see perm_decode)
   int Q1, Q2;       // rows per parity class in segment 1 / 2 (= N * OH/2 * OW/2)
 };
@@ -491,21 +492,6 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const Args a) {
   const int lc = pch ^ ((r0 >> 1) & 7);
   const char* zsrc = zero + pch * 16;
   const char* INl = IN + lc * 16;
-  int a_base[4], a_yx[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int m = m0 + r0 + 64 * j;
-    if (m < a.M) {
-      const wseg_rowgeo rg = a.perm ? perm_decode(a, m).g : wseg_decode_row(d, m);
-      int iy0, ix0;
-      if (d.mode == 0) { iy0 = rg.oy * d.stride - d.pad; ix0 = rg.ox * d.stride - d.pad; }
-      else             { iy0 = rg.oy + d.pad;            ix0 = rg.ox + d.pad; }
-      a_base[j] = (int)rg.in_base;
-      a_yx[j] = (rg.n_glob >= d.N ? (int)0x80000000 : 0) | ((iy0 + 0x2000) << 16) | (ix0 + 0x2000);
-    } else {
-      a_base[j] = -1; a_yx[j] = (0x2000 << 16) | 0x2000;
-    }
-  }
   // tap list (4-bit entries): all taps, or — parity-permuted rows, tile inside one class — only the class's valid taps
   unsigned long long tl = 0x876543210ull;
   int ntaps = a.taps;
@@ -521,12 +507,44 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const Args a) {
       if (ntaps == 0) { tl = 0ull; ntaps = 1; }    // (a class without taps: one all-padding tap keeps the pipeline uniform)
     }
   }
-  const char* aptr[4];
-  unsigned a_live = 0;                             // bit j: row j reads real data (pointer advances by 128 B per K-tile)
   const char* bptr0 = Wp + ((size_t)(n0 + r0) * a.taps * d.IC + (size_t)lc * CH) * ES;   // OC % 256 == 0 (host-checked)
   const char* bptr = bptr0 + (size_t)(tl & 15ull) * d.IC * ES;
   int b_ti = 0, b_cc = 0;                          // (perm only) position of the NEXT B tile in the tap list
   const int brs = 64 * a.taps * d.IC * ES;         // bytes between B rows r0 + 64*j
+  auto issue_b = [&](int h, int buf) {
+    char* dst = smem + buf * TILE256 + (2 + h) * HALF256 + wid * 1024;
+    glds16(bptr + (2 * h) * brs, dst);
+    glds16(bptr + (2 * h + 1) * brs, dst + 8192);
+  };
+  auto advance_b = [&]() {
+    bptr += 128;                                   // (the full tap list is contiguous in K: nothing else to do)
+    if (a.perm && ++b_cc == a.cpt) { b_cc = 0; ++b_ti; bptr = bptr0 + (size_t)((tl >> (4 * b_ti)) & 15ull) * d.IC * ES; }
+  };
+
+  // The weight tiles need no pixel geometry: their LDS-DMA is issued BEFORE the row decode (three integer divisions per row)
+  // and the tap set-up, which then run in the shadow of the DMA latency instead of in front of it.
+  const int nt = ntaps * a.cpt;
+  if (a.early_b) {
+    issue_b(0, 0); issue_b(1, 0); advance_b();
+    if (nt > 1) { issue_b(0, 1); issue_b(1, 1); advance_b(); }
+  }
+  int a_base[4], a_yx[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int m = m0 + r0 + 64 * j;
+    if (m < a.M) {
+      const wseg_rowgeo rg = a.perm ? perm_decode(a, m).g : wseg_decode_row(d, m);
+      int iy0, ix0;
+      if (d.mode == 0) { iy0 = rg.oy * d.stride - d.pad; ix0 = rg.ox * d.stride - d.pad; }
+      else             { iy0 = rg.oy + d.pad;            ix0 = rg.ox + d.pad; }
+      a_base[j] = (int)rg.in_base;
+      a_yx[j] = (rg.n_glob >= d.N ? (int)0x80000000 : 0) | ((iy0 + 0x2000) << 16) | (ix0 + 0x2000);
+    } else {
+      a_base[j] = -1; a_yx[j] = (0x2000 << 16) | 0x2000;
+    }
+  }
+  const char* aptr[4];
+  unsigned a_live = 0;                             // bit j: row j reads real data (pointer advances by 128 B per K-tile)
   auto set_tap = [&](int tap) {
     const int ky = tap / d.KW, kx = tap - ky * d.KW;
     a_live = 0;
@@ -560,29 +578,20 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const Args a) {
     for (int j = 0; j < 4; ++j) aptr[j] += ((a_live >> j) & 1u) << 7;
     if (++a_cc == a.cpt) { a_cc = 0; if (++a_tap < ntaps) set_tap((int)((tl >> (4 * a_tap)) & 15ull)); }
   };
-  auto issue_b = [&](int h, int buf) {
-    char* dst = smem + buf * TILE256 + (2 + h) * HALF256 + wid * 1024;
-    glds16(bptr + (2 * h) * brs, dst);
-    glds16(bptr + (2 * h + 1) * brs, dst + 8192);
-  };
-  auto advance_b = [&]() {
-    bptr += 128;                                   // (the full tap list is contiguous in K: nothing else to do)
-    if (a.perm && ++b_cc == a.cpt) { b_cc = 0; ++b_ti; bptr = bptr0 + (size_t)((tl >> (4 * b_ti)) & 15ull) * d.IC * ES; }
-  };
-
   f32x4 acc[8][4];
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int nt = ntaps * a.cpt;
-  // prologue: tile 0 entirely + the B halves of tile 1 (what p3/p4 of a "tile -1" would have issued)
+  // prologue: tile 0's A halves (B(0), B(1) are already in flight); everything must have landed before the first reads
   set_tap((int)(tl & 15ull));
   issue_a(0, 0); issue_a(1, 0); advance_a();
-  issue_b(0, 0); issue_b(1, 0); advance_b();
-  if (nt > 1) { issue_b(0, 1); issue_b(1, 1); advance_b(); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (!a.early_b) {                                // (A/B switch WSEG_CONV_EARLYB=0: weights after the row decode, as before)
+    issue_b(0, 0); issue_b(1, 0); advance_b();
+    if (nt > 1) { issue_b(0, 1); issue_b(1, 1); advance_b(); }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
   bf16x8 af[2][4], b0[2][2], b1[2][2];             // [ks][tile]: A sub-tile (64 rows), B sub-tiles hb = 0 / 1 (32 cols each)
@@ -1058,6 +1067,8 @@ extern "C" int wseg_conv_igemm(const wseg_conv_desc* d, void* stream) {
   Args a;
   a.d = *d;
   a.perm = 0; a.Q1 = a.Q2 = 0;
+  static const int early_b = getenv("WSEG_CONV_EARLYB") ? atoi(getenv("WSEG_CONV_EARLYB")) : 1;
+  a.early_b = early_b;
   a.M = (int)M;
   a.taps = d->KH * d->KW;
   a.cpt = d->IC * es / ROWB;
