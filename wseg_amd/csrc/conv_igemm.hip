@@ -465,11 +465,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const Args a) {
 // per K-tile (B0/B1(u+2) stay in flight) and one raw s_barrier per phase.  The im2col gather is again only the
 // per-lane source address (4 pixel rows per thread, re-derived once per tap); padded taps read the zero page.
 // Epilogue: 4 passes of 64 rows through a 65-KiB f32 LDS image, same fused epilogue as the 128^2 kernel.
-constexpr int HALF256 = 16384, TILE256 = 4 * HALF256, EPI_LD256 = 256 + 4;
+constexpr int HALF256 = 16384, TILE256 = 4 * HALF256;
 
 template <int EPI, int STG>
 __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const Args a) {
-  constexpr int DT = WSEG_BF16, ES = 2, CH = 8;
+  constexpr int ES = 2, CH = 8;
   __shared__ __attribute__((aligned(16))) char smem[2 * TILE256];
   const wseg_conv_desc& d = a.d;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -720,11 +720,11 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const Args a) {
 // the B fragments of phase A are kept in registers for phase B):
 //     pA(u): A0(u+1), A1(u+1)      pB(u): B(u+2), counted s_waitcnt vmcnt(2)
 // 85 FLOP per filled byte (the 128^2 kernel: 64) and one barrier per 16 MFMAs, as in the 256^2 kernel.
-constexpr int TILE2N = 3 * HALF256, EPI_LD2N = 128 + 4;
+constexpr int TILE2N = 3 * HALF256;
 
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void conv_igemm256x128_kernel(const Args a) {
-  constexpr int DT = WSEG_BF16, ES = 2, CH = 8;
+  constexpr int ES = 2, CH = 8;
   __shared__ __attribute__((aligned(16))) char smem[3 * TILE2N];   // THREE K-tile buffers (144 KiB): see the loop
   const wseg_conv_desc& d = a.d;
   const int tid = threadIdx.x, lane = tid & 63;
