@@ -107,7 +107,7 @@ GRAD_KEYS = ["fc8.weight", "fc_proj.weight", "f9.weight", "f8_3.weight", "f8_4.w
              "b3.conv_branch2a.weight", "b3_1.conv_branch2b1.weight"]
 
 
-def step_golden(R, visualization, out_dir, name, n, size, seed, sd, py_seed):
+def step_golden(R, visualization, out_dir, name, n, size, seed, sd, py_seed, edge_labels=False):
     model = R.Net()
     model.load_state_dict(sd)
     model.train()
@@ -115,6 +115,8 @@ def step_golden(R, visualization, out_dir, name, n, size, seed, sd, py_seed):
     install_masks(model, masks)
     img = synth.synthetic_images(n, size, seed)
     lab = synth.synthetic_labels(n, seed)
+    if edge_labels:                                  # an image without any foreground class, one with all twenty
+        lab = lab.clone(); lab[0] = 0.0; lab[1] = 1.0
     helpers, body = body_source()
     ns = {"torch": torch, "F": F, "np": np, "random": random, "visualization": visualization,
           "model": model, "pack": (None, img, lab), "args": types.SimpleNamespace(bg_threshold=0.20)}
@@ -140,7 +142,7 @@ def step_golden(R, visualization, out_dir, name, n, size, seed, sd, py_seed):
         grads["gslice/" + k] = flat[::step][:4096].numpy().copy()
     np.savez_compressed(
         os.path.join(out_dir, name + ".npz"), n=n, size=size, seed=seed, py_seed=py_seed,
-        n_with_grad=n_with_grad,
+        n_with_grad=n_with_grad, label=lab.numpy(),
         **{"s/" + k: np.array(v) for k, v in scal.items()},
         protos1=ns["prototypes1"].numpy(), protos2=ns["prototypes2"].numpy(),
         pseudo1=ns["pseudo_label1"].numpy().astype(np.uint8), pseudo2=ns["pseudo_label2"].numpy().astype(np.uint8),
@@ -236,6 +238,11 @@ def main():
     if "step" in todo:
         step_golden(R, visualization, a.out, "step_S160_N2", 2, 160, 21, sd, py_seed=7)
         step_golden(R, visualization, a.out, "step_S128_N3", 3, 128, 22, sd, py_seed=8)
+    if "step_edge" in todo or "step" in todo:
+        # an image with all twenty classes carries large gradients through dozens of ReLU pre-activations that sit within f32
+        # summation noise of zero (scripts/relu_near_ties.py): backbone gradients of this fixture are compared at 5e-2, the
+        # scalars and head gradients at the usual bars (tests/test_gpu_loss.py)
+        step_golden(R, visualization, a.out, "step_edge_S64_N3", 3, 64, 16, sd, py_seed=5, edge_labels=True)
     if "sgd" in todo:
         sgd_golden(torchutils, a.out)
     if "topk" in todo:

@@ -39,30 +39,38 @@ def _trainer(proc_sd, precision, loss_impl, n, seed, py_seed, lr=0.01):
 
 
 @pytest.mark.parametrize("loss_impl", ["hip", "aten"])
-@pytest.mark.parametrize("name", ["step_S160_N2", "step_S128_N3"])
+@pytest.mark.parametrize("name", ["step_S160_N2", "step_S128_N3", "step_edge_S64_N3"])
 def test_step_matches_reference_fixture(golden_dir, proc_sd, name, loss_impl):
     from wseg_amd import synth
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     n, size, seed, py_seed = int(g["n"]), int(g["size"]), int(g["seed"]), int(g["py_seed"])
     model, opt, tr = _trainer(proc_sd, "fp32", loss_impl, n, seed, py_seed)
     w_before = model._engine.conv_param("fc8").detach().clone() if model._engine.flat_w is not None else None
-    got = tr.step(synth.synthetic_images(n, size, seed).cuda(), synth.synthetic_labels(n, seed).cuda())
+    lab = torch.from_numpy(g["label"]) if "label" in g.files else synth.synthetic_labels(n, seed)   # (edge fixture: an image with no
+    got = tr.step(synth.synthetic_images(n, size, seed).cuda(), lab.cuda())                            #  class, one with all twenty)
     for k in SCALARS:
         ref = float(g["s/" + k])
         assert abs(float(got[k]) - ref) <= 1e-4 * max(1.0, abs(ref)), (k, float(got[k]), ref)
     params = dict(model.named_parameters())
+    # Head-layer weight gradients depend on the forward values and the loss gradient only: 2e-3 of the slice maximum for every
+    # fixture.  Backbone weight gradients also pass through the ReLU masks of every later layer; the edge fixture's
+    # all-twenty-classes image at 64x64 puts dozens of pre-activations within f32 summation noise of zero under 10-50 % of
+    # their layer's largest gradient (scripts/relu_near_ties.py), and which of them flip depends on the summation order, so
+    # its backbone bar is 5e-2 — a mishandled empty / full label row would show in the scalars and the head gradients.
+    head = ("fc8.", "fc_proj.", "f9.", "f8_3.", "f8_4.")
     for key in g.files:
         if not key.startswith("gslice/"):
             continue
         k = key[len("gslice/"):]
+        tol = 5e-2 if ("edge" in name and not k.startswith(head)) else 2e-3
         gr = params[k].grad.detach().cpu()
         flat = gr.reshape(-1)
         stepv = max(1, flat.numel() // 4096)
         ref = g[key]
         scale = np.abs(ref).max() + 1e-12
-        assert np.abs(flat[::stepv][:4096].numpy() - ref).max() / scale < 2e-3, k
+        assert np.abs(flat[::stepv][:4096].numpy() - ref).max() / scale < tol, k
         gn = float(g["gnorm/" + k])
-        assert abs(float(gr.double().norm()) - gn) < 2e-3 * gn, k
+        assert abs(float(gr.double().norm()) - gn) < tol * gn, k
     assert opt.global_step == 1
 
 

@@ -36,7 +36,7 @@ def test_net_forward_eval(golden_dir, proc_sd, name):
     assert (cam_rv.argmax(1).numpy() == g["cam_rv_argmax"]).mean() > 0.9999
 
 
-@pytest.mark.parametrize("name", ["step_S160_N2", "step_S128_N3"])
+@pytest.mark.parametrize("name", ["step_S160_N2", "step_S128_N3", "step_edge_S64_N3"])
 def test_train_step_loss_and_grads(golden_dir, proc_sd, name):
     g = _load(golden_dir, name)
     n, size, seed, py_seed = int(g["n"]), int(g["size"]), int(g["seed"]), int(g["py_seed"])
@@ -45,7 +45,7 @@ def test_train_step_loss_and_grads(golden_dir, proc_sd, name):
     for k in keys:
         sd[k] = sd[k].clone().requires_grad_(True)
     img = synth.synthetic_images(n, size, seed)
-    lab = synth.synthetic_labels(n, seed)
+    lab = torch.from_numpy(g["label"]) if "label" in g.files else synth.synthetic_labels(n, seed)   # (edge fixture: explicit labels)
     m1 = synth.synthetic_dropout_masks(n, seed * 2 + 0)
     m2 = synth.synthetic_dropout_masks(n, seed * 2 + 1)
     extras = {}
