@@ -56,6 +56,10 @@ if __name__ == "__main__":
     torch.cuda.set_device(0)
     if world > 1:
         dist.init_process_group("gloo")
+    elif os.environ.get("WSEG_FORCE_DIST", "0") == "1":     # one-rank RCCL group: the real backend's call path on one GPU
+        for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29534"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+            os.environ.setdefault(k, v)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
     run(out_path, n_global, size, world, rank)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()

@@ -167,7 +167,8 @@ def step(model, img1, img2, label20, bg_threshold=0.20, rng=None, rng_parity=Fal
     eng = model._engine
     dev = img1.device
     N = img1.shape[0]
-    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    from .train import dist_state
+    world, distributed = dist_state()
     label20 = label20.to(dev).float().contiguous()
     eng.ensure_flat(dev)
     eng.attach_grads()
@@ -201,7 +202,7 @@ def step(model, img1, img2, label20, bg_threshold=0.20, rng=None, rng_parity=Fal
     for st in side:
         main.wait_stream(st)
     gathered = cand
-    if world > 1:                                           # global-batch prototypes: ONE all-gather of both views' candidates (694 KB)
+    if distributed:                                         # global-batch prototypes: ONE all-gather of both views' candidates (694 KB)
         gathered = _f32(world, 2, _CAND_L, dev=dev)
         dist.all_gather_into_tensor(gathered.view(world * 2, _CAND_L), cand)
     for vi, v in enumerate(views):
@@ -209,8 +210,8 @@ def step(model, img1, img2, label20, bg_threshold=0.20, rng=None, rng_parity=Fal
     # ---- pixel-to-prototype similarities + hard-pixel records on a side stream, concurrently with the ER / ECR chain below
     # (the radix-select kernel is also the faster one on a single rank — 47 vs 118 us; the sort-based kernel remains the
     #  RNG-parity path, which replays the reference's host random stream)
-    global_intra = world > 1 or (not rng_parity and os.environ.get("WSEG_INTRA_GLOBAL", "1") == "1")
-    rank = dist.get_rank() if world > 1 else 0
+    global_intra = distributed or (not rng_parity and os.environ.get("WSEG_INTRA_GLOBAL", "1") == "1")
+    rank = dist.get_rank() if distributed else 0
     cst = side[1]
     cst.wait_stream(main)
     with torch.cuda.stream(cst):
@@ -243,7 +244,7 @@ def step(model, img1, img2, label20, bg_threshold=0.20, rng=None, rng_parity=Fal
     L.ecr_backward(dlt, res, Gr, 2 * N, 21 * npix, K_ecr, 1.0 / (N * K_ecr))
     v1.Gr, v2.Gr = Gr[:N], Gr[N:]
     main.wait_stream(cst)
-    if global_intra and world > 1:                          # (collectives stay on the main stream, in program order)
+    if global_intra and distributed:                        # (collectives stay on the main stream, in program order)
         grec = _f32(world, 2, 3, P, dev=dev)
         dist.all_gather_into_tensor(grec.view(world * 6, P), rec.view(6, P))
     elif rng_parity and not global_intra:

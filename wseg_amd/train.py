@@ -15,6 +15,17 @@ from . import _lib as L
 from . import loss_aten
 
 
+def dist_state():
+    """(world size, whether the data-parallel exchanges run).  They run whenever there is more than one rank;
+    WSEG_FORCE_DIST=1 also runs them in an initialised one-rank group — the way the RCCL call path (candidate and
+    hard-pixel all-gathers, bucketed gradient all-reduce) is exercised on a one-GPU box, where the results must equal the
+    local path's."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1, False
+    world = dist.get_world_size()
+    return world, world > 1 or os.environ.get("WSEG_FORCE_DIST", "0") == "1"
+
+
 def second_view(img1, size=128):
     """contrast_train.py:131-134 on the device (the reference does it on the host tensor)."""
     N, C, H, W = img1.shape
@@ -33,9 +44,9 @@ class Trainer:
         self.rng_parity = rng_parity
         self.loss_impl = loss_impl
         self.bg_topk_idx = bg_topk_idx
-        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.world, self.distributed = dist_state()
         self._pending = []
-        if self.world > 1 and loss_impl == "hip" and os.environ.get("WSEG_BUCKETS", "1") != "0":   # (one joint backward)
+        if self.distributed and loss_impl == "hip" and os.environ.get("WSEG_BUCKETS", "1") != "0":   # (one joint backward)
             # Gradient all-reduce overlapped with backward: the flat gradient buffer completes back to front, so each
             # bucket (b7 + heads, b5..b6, b4*, b3*: 154 / 143 / 109 / 13 MB) is reduced as soon as its last weight
             # gradient is enqueued — RCCL runs on its own stream behind those kernels while dgrad/wgrad continue.
@@ -67,7 +78,7 @@ class Trainer:
             from . import loss_hip
             losses = loss_hip.step(model, img1, img2, label20, self.bg_threshold, self.rng, self.rng_parity,
                                    self.bg_topk_idx)
-        if self.world > 1:
+        if self.distributed:
             if self._pending:                               # bucketed all-reduces launched during backward
                 for work in self._pending:
                     work.wait()
