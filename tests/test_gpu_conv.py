@@ -81,7 +81,7 @@ def test_conv_fwd_dgrad_wgrad(case, dt, bm):
     assert np.abs(dwg.cpu().numpy() - 2 * ref).max() / scale < 2 * wtol
 
 
-@pytest.mark.parametrize("dt,OC,bm", [("f32", 128, 0), ("bf16", 128, 0), ("bf16", 256, 256), ("bf16", 128, 258), ("bf16", 128, 259)])
+@pytest.mark.parametrize("dt,OC,bm", [("f32", 128, 0), ("bf16", 128, 0), ("bf16", 256, 256), ("bf16", 256, 224), ("bf16", 128, 258), ("bf16", 128, 259)])
 def test_conv_epilogues(dt, OC, bm):
     """fused BN-ReLU-dropout second output (forward) and masked-scale (+residual) epilogue (backward);
     bm=256: the 256x256 phase-pipelined kernel (300 rows = one full + one partial row tile)."""
@@ -162,16 +162,16 @@ def test_conv_many_row_tiles(dt):
     np.testing.assert_allclose(yg.float().cpu().numpy(), _nhwc(y).numpy(), **tol)
 
 
-@pytest.mark.parametrize("dt,bm", [("f32", 0), ("bf16", 0), ("bf16", 256), ("bf16", 2560), ("bf16", 259)])
+@pytest.mark.parametrize("dt,bm", [("f32", 0), ("bf16", 0), ("bf16", 256), ("bf16", 2560), ("bf16", 224), ("bf16", 2240), ("bf16", 259)])
 @pytest.mark.parametrize("geom", [(3, 1, 2), (3, 2, 1), (1, 2, 1)])
 def test_conv_two_row_segments(dt, bm, geom):
     """Two views batched in one launch: rows [0,N*OH*OW) use geometry 1, the rest geometry 2 (fwd, dgrad, wgrad)."""
     from wseg_amd import _lib as L
     k, s, d = geom
     tdt = torch.float32 if dt == "f32" else torch.bfloat16
-    N, IC, OC = 2, (256 if bm >= 256 else 64), 256      # bm>=256: dgrad (OC = IC) takes the big-tile kernels too
-    (H1, W1), (H2, W2) = (20, 18), ((8, 12) if bm == 2560 else (9, 11))   # 2560: even sizes in both segments (parity-permuted s2 dgrad)
-    bm = 256 if bm == 2560 else bm
+    N, IC, OC = 2, (256 if bm >= 224 else 64), 256      # bm>=224: dgrad (OC = IC) takes the big-tile kernels too
+    (H1, W1), (H2, W2) = (20, 18), ((8, 12) if bm in (2560, 2240) else (9, 11))   # 2560 / 2240: even sizes in both segments (parity-permuted s2 dgrad)
+    bm = {2560: 256, 2240: 224}.get(bm, bm)
     pad = d * (k // 2)
     osz = lambda h: (h + 2 * pad - d * (k - 1) - 1) // s + 1
     xs = [_rand((N, IC, H1, W1), 1).to(tdt).float().requires_grad_(True), _rand((N, IC, H2, W2), 2).to(tdt).float().requires_grad_(True)]
@@ -248,6 +248,10 @@ def test_conv256_fwd_dgrad(case):
     ysp = torch.full_like(yg, float("nan"))
     L.conv_igemm(xg, wf, ysp, N=N, IH=H, IW=W, IC=IC, OH=OH, OW=OW, OC=OC, KH=k, KW=k, stride=s, dil=d, pad=pad, bm_hint=257)
     np.testing.assert_allclose(ysp.float().cpu().numpy(), _nhwc(y.detach()).numpy(), **tol)
+    # 224-row tiles of the 256-tile kernel (each wave row owns 112 rows)
+    y7 = torch.full_like(yg, float("nan"))
+    L.conv_igemm(xg, wf, y7, N=N, IH=H, IW=W, IC=IC, OH=OH, OW=OW, OC=OC, KH=k, KW=k, stride=s, dil=d, pad=pad, bm_hint=224)
+    np.testing.assert_allclose(y7.float().cpu().numpy(), _nhwc(y.detach()).numpy(), **tol)
     # the 256 x 128 tile kernel (OC % 128 == 0)
     y2n = torch.full_like(yg, float("nan"))
     L.conv_igemm(xg, wf, y2n, N=N, IH=H, IW=W, IC=IC, OH=OH, OW=OW, OC=OC, KH=k, KW=k, stride=s, dil=d, pad=pad, bm_hint=258)
@@ -266,6 +270,10 @@ def test_conv256_fwd_dgrad(case):
         L.conv_igemm(_nhwc(dy).to(dev, tdt), wt, dxg, N=N, IH=OH, IW=OW, IC=OC, OH=H, OW=W, OC=IC, KH=k, KW=k, stride=s, dil=d,
                      pad=pad, mode=1, bm_hint=256)
         np.testing.assert_allclose(dxg.float().cpu().numpy(), _nhwc(x.grad).numpy(), **tol)
+        dx7 = torch.full_like(dxg, float("nan"))
+        L.conv_igemm(_nhwc(dy).to(dev, tdt), wt, dx7, N=N, IH=OH, IW=OW, IC=OC, OH=H, OW=W, OC=IC, KH=k, KW=k, stride=s, dil=d,
+                     pad=pad, mode=1, bm_hint=224)
+        np.testing.assert_allclose(dx7.float().cpu().numpy(), _nhwc(x.grad).numpy(), **tol)
 
 
 def test_batched_transposed_pack_bf16_matches_f32_source():

@@ -467,16 +467,23 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const Args a) {
 // Epilogue: 4 passes of 64 rows through a 65-KiB f32 LDS image, same fused epilogue as the 128^2 kernel.
 constexpr int HALF256 = 16384, TILE256 = 4 * HALF256;
 
-template <int EPI, int STG>
+//
+// NI = 7: a 224-row tile in the same buffers (each wave row owns 112 rows: LDS rows 112..127 of the A half-slots are fed from
+// the zero page and never read, phase 2 runs 3 row blocks instead of 4).  For the layers whose 256-row tiles fill the last
+// round of 256 CUs badly (424 tiles = 1.66 rounds for the 512-channel 56x56 layers) 486 tiles of 7/8 the work are 12.5 % less
+// time per CU; the host picks it when that arithmetic says so.
+template <int EPI, int STG, int NI = 8>
 __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const Args a) {
   constexpr int ES = 2, CH = 8;
+  constexpr int RH = NI * 16, BMT = 2 * RH;        // rows per wave row / per tile
+  static_assert(NI == 8 || (NI == 7 && STG >= 2), "224-row tiles exist for the 2-phase schedules only");
   __shared__ __attribute__((aligned(16))) char smem[2 * TILE256];
   const wseg_conv_desc& d = a.d;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tile = xcd_remap(blockIdx.x, a.nwg);
   const int tm = tile / a.ntn, tn = tile - tm * a.ntn;
-  const int m0 = a.row0 + tm * 256, n0 = tn * 256;
+  const int m0 = a.row0 + tm * BMT, n0 = tn * 256;
   const int wr = wid >> 2, wc = wid & 3;
   const int frow = lane & 15, fk = lane >> 4, sw = (lane >> 1) & 7;
 
@@ -496,7 +503,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const Args a) {
   unsigned long long tl = 0x876543210ull;
   int ntaps = a.taps;
   if (a.perm) {
-    const int c0 = perm_decode(a, m0).cls, c1 = perm_decode(a, min(m0 + 255, a.M - 1)).cls;
+    const int c0 = perm_decode(a, m0).cls, c1 = perm_decode(a, min(m0 + BMT - 1, a.M - 1)).cls;
     if (c0 == c1) {
       const int py = (c0 >> 1) & 1, px = c0 & 1;
       tl = 0ull; ntaps = 0;
@@ -531,8 +538,9 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const Args a) {
   int a_base[4], a_yx[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int m = m0 + r0 + 64 * j;
-    if (m < a.M) {
+    const int rho = r0 + 64 * (j & 1);             // LDS row inside half-slot j >> 1 = tile row (j >> 1) * RH + rho
+    const int m = m0 + (j >> 1) * RH + rho;
+    if (rho < RH && m < a.M) {
       const wseg_rowgeo rg = a.perm ? perm_decode(a, m).g : wseg_decode_row(d, m);
       int iy0, ix0;
       if (d.mode == 0) { iy0 = rg.oy * d.stride - d.pad; ix0 = rg.ox * d.stride - d.pad; }
@@ -578,9 +586,9 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const Args a) {
     for (int j = 0; j < 4; ++j) aptr[j] += ((a_live >> j) & 1u) << 7;
     if (++a_cc == a.cpt) { a_cc = 0; if (++a_tap < ntaps) set_tap((int)((tl >> (4 * a_tap)) & 15ull)); }
   };
-  f32x4 acc[8][4];
+  f32x4 acc[NI][4];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -600,7 +608,8 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const Args a) {
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        af[ks][i] = *reinterpret_cast<const bf16x8*>(aH + (ha * 64 + i * 16 + frow) * 128 + (((ks * 4 + fk) ^ sw) << 4));
+        if (ha * 4 + i < NI)
+          af[ks][i] = *reinterpret_cast<const bf16x8*>(aH + (ha * 64 + i * 16 + frow) * 128 + (((ks * 4 + fk) ^ sw) << 4));
   };
   auto ldB = [&](const char* bH, int hb, bf16x8 (&bf)[2][2]) {
 #pragma unroll
@@ -615,8 +624,9 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const Args a) {
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                         \
       _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                          \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                        \
-          acc[(HA) * 4 + i][(HB) * 2 + j] =                                                                  \
-              __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][i], BF[ks][j], acc[(HA) * 4 + i][(HB) * 2 + j], 0, 0, 0); \
+          if ((HA) * 4 + i < NI)              /* (unrolled counter: folds at compile time) */                \
+            acc[(HA) * 4 + i][(HB) * 2 + j] =                                                                \
+                __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][i], BF[ks][j], acc[(HA) * 4 + i][(HB) * 2 + j], 0, 0, 0); \
     __builtin_amdgcn_s_setprio(0);                                                                           \
   } while (0)
 
@@ -710,7 +720,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const Args a) {
 
   // ---- epilogue, wave-local (see wave_local_epilogue)
   __syncthreads();                                 // every wave is done with the pipeline buffers
-  wave_local_epilogue<EPI, 8>(a, smem, wid, lane, m0 + wr * 128, wc * 64, n0, acc);
+  wave_local_epilogue<EPI, NI>(a, smem, wid, lane, m0 + wr * RH, wc * 64, n0, acc);
 }
 
 
@@ -1094,7 +1104,7 @@ extern "C" int wseg_conv_igemm(const wseg_conv_desc* d, void* stream) {
     const long rounds = (t256 + 255) / 256;
     static const int auto256 = getenv("WSEG_CONV256") ? atoi(getenv("WSEG_CONV256")) : 1;   // (0: A/B switch)
     static const int split_tail = getenv("WSEG_CONV_SPLIT") ? atoi(getenv("WSEG_CONV_SPLIT")) : 0;
-    big = d->bm_hint == 256 || d->bm_hint == 257 ||
+    big = d->bm_hint == 256 || d->bm_hint == 257 || d->bm_hint == 224 ||
           (auto256 && ((t256 >= 200 && (double)t256 / (double)(rounds * 256) >= 0.80) || (split_tail && d->bm_hint == 0 && t256 >= 256)));
     if (big)
       WSEG_CHECK(d->IH <= 16384 && d->IW <= 16384 && d->OH <= 16384 && d->OW <= 16384 && d->pad <= 4096 &&
@@ -1138,25 +1148,41 @@ extern "C" int wseg_conv_igemm(const wseg_conv_desc* d, void* stream) {
       a.Q1 = d->N * (d->OH / 2) * (d->OW / 2);
       a.Q2 = d->N * (d->OH2 / 2) * (d->OW2 / 2);
     }
+    static const int stagger = getenv("WSEG_CONV_STAGGER") ? atoi(getenv("WSEG_CONV_STAGGER")) : 2;   // 0: 4 phases lock-step, 1: 4 phases ping-pong, 2: 2 phases ping-pong (best), 3: 2 phases lock-step
     a.ntn = (d->OC + 255) / 256;
-    const long ntm = (M + 255) / 256;
+    // 224-row tiles (NI = 7) when they need less CU time than 256-row tiles: rounds(tiles) x rows per tile
+    static const int auto224 = getenv("WSEG_CONV224") ? atoi(getenv("WSEG_CONV224")) : 1;   // (0: A/B switch)
+    const long t8 = ((M + 255) / 256) * a.ntn, t7 = ((M + 223) / 224) * a.ntn;
+    const bool ni7 = (stagger == 2 || stagger == 3) && d->bm_hint != 256 && d->bm_hint != 257 &&
+                     (d->bm_hint == 224 || (auto224 && d->bm_hint == 0 && (auto224 == 2 || ((t7 + 255) / 256) * 7 < ((t8 + 255) / 256) * 8)));
+    const int bmt = ni7 ? 224 : 256;
+    const long ntm = (M + bmt - 1) / bmt;
     long main_tm = ntm;                              // row tiles given to the 256-tile kernel
     // WSEG_CONV_SPLIT=1 (experiment, off): only the FULL rounds go to the 256-tile kernel and the remaining rows to the
     // 128-tile kernel (quarter-size tiles, a shorter tail).  Measured: no gain (26.35 vs 26.55 ms/step of conv time,
     // layers move +-8 % either way) — a partly filled last round runs faster per tile, rounds are not discrete here either.
     static const int split_tail = getenv("WSEG_CONV_SPLIT") ? atoi(getenv("WSEG_CONV_SPLIT")) : 0;
     const long t256 = ntm * a.ntn, full = t256 / 256, rem = t256 % 256;
-    if (!a.perm && ((split_tail && d->bm_hint == 0 && full >= 1 && rem > 0 && rem <= 208 && 256 % a.ntn == 0) || d->bm_hint == 257))
+    if (!a.perm && !ni7 && ((split_tail && d->bm_hint == 0 && full >= 1 && rem > 0 && rem <= 208 && 256 % a.ntn == 0) || d->bm_hint == 257))
       main_tm = d->bm_hint == 257 ? std::max(1L, ntm / 2) : full * 256 / a.ntn;
     a.nwg = (int)(main_tm * a.ntn);
-    static const int stagger = getenv("WSEG_CONV_STAGGER") ? atoi(getenv("WSEG_CONV_STAGGER")) : 2;   // 0: 4 phases lock-step, 1: 4 phases ping-pong, 2: 2 phases ping-pong (best), 3: 2 phases lock-step
 #define WSEG_LAUNCH_256(STG_)                                                                                          \
   do {                                                                                                                 \
     if (d->epi == 0) hipLaunchKernelGGL((conv_igemm256_kernel<0, STG_>), dim3(a.nwg), dim3(512), 0, s, a);              \
     else if (d->epi == 1) hipLaunchKernelGGL((conv_igemm256_kernel<1, STG_>), dim3(a.nwg), dim3(512), 0, s, a);         \
     else hipLaunchKernelGGL((conv_igemm256_kernel<2, STG_>), dim3(a.nwg), dim3(512), 0, s, a);                          \
   } while (0)
-    if (stagger == 1) WSEG_LAUNCH_256(1);
+    if (ni7) {
+      if (stagger == 2) {
+        if (d->epi == 0) hipLaunchKernelGGL((conv_igemm256_kernel<0, 2, 7>), dim3(a.nwg), dim3(512), 0, s, a);
+        else if (d->epi == 1) hipLaunchKernelGGL((conv_igemm256_kernel<1, 2, 7>), dim3(a.nwg), dim3(512), 0, s, a);
+        else hipLaunchKernelGGL((conv_igemm256_kernel<2, 2, 7>), dim3(a.nwg), dim3(512), 0, s, a);
+      } else {
+        if (d->epi == 0) hipLaunchKernelGGL((conv_igemm256_kernel<0, 3, 7>), dim3(a.nwg), dim3(512), 0, s, a);
+        else if (d->epi == 1) hipLaunchKernelGGL((conv_igemm256_kernel<1, 3, 7>), dim3(a.nwg), dim3(512), 0, s, a);
+        else hipLaunchKernelGGL((conv_igemm256_kernel<2, 3, 7>), dim3(a.nwg), dim3(512), 0, s, a);
+      }
+    } else if (stagger == 1) WSEG_LAUNCH_256(1);
     else if (stagger == 2) WSEG_LAUNCH_256(2);
     else if (stagger == 3) WSEG_LAUNCH_256(3);
     else {
