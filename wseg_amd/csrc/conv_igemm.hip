@@ -176,53 +176,59 @@ __device__ __forceinline__ void epilogue_image(const wseg_conv_desc& d, int M, c
 // store work.  (A block-wide LDS image needed 8 barriers and 8 serialised load round trips per 256x256 tile.)  Stores are full
 // 128-B lines: 8 lanes x 16 B per output row.  mw0 = first row of the wave's tile, col0 = its first column inside the
 // column tile n0.  The caller has made sure (barrier) that no wave still reads the pipeline buffers.
-template <int EPI, int NI>
-__device__ __forceinline__ void wave_local_epilogue(const Args& a, char* smem, int wid, int lane, int mw0, int col0, int n0,
-                                                    const f32x4 (&acc)[NI][4]) {
+// Operand prefetch: the residual / mask vectors of FOUR steps are requested together, before the first scratch round trip
+// (raw 16-B vectors, 64 registers), so a tile's epilogue exposes two global-load latencies instead of one per step
+// (the per-step version: 7-8 x ~1.5 us of a ~100 us tile).  When r_pre and r_post are both present (never in this network),
+// r_post stays a per-step load; the per-image dropout factors (b6 / b7 only, L2-resident) too.
+__device__ __forceinline__ uint4 ldg16_bf16(const void* p, size_t i) { return *reinterpret_cast<const uint4*>((const bf16_t*)p + i); }
+__device__ __forceinline__ void unpack8_bf16(const uint4& a, float (&v)[8]) {
+  const unsigned w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { v[2 * j] = __uint_as_float(w[j] << 16); v[2 * j + 1] = __uint_as_float(w[j] & 0xFFFF0000u); }
+}
+
+template <int EPI, int NI, int I0, int NB>
+__device__ __forceinline__ void wave_local_epilogue_batch(const Args& a, float* wimg, int lane, int mw0, int oc, bool col_ok,
+                                                          const float (&sc)[8], const float (&sh)[8], const f32x4 (&acc)[NI][4]) {
   constexpr int DT = WSEG_BF16;
+  constexpr int WLD = 64 + 4;
   const wseg_conv_desc& d = a.d;
   const int frow = lane & 15, fk = lane >> 4;
-  constexpr int WLD = 64 + 4;                      // scratch row stride (floats): conflict-free for both access patterns
-  float* wimg = reinterpret_cast<float*>(smem) + wid * (16 * WLD);
-  const int vr = lane >> 3, vg = lane & 7;         // this lane's vectors: rows vr and vr + 8 of the step, column group vg
-  const int oc_raw = n0 + col0 + vg * 8;
-  const bool col_ok = oc_raw < d.OC;
-  const int oc = col_ok ? oc_raw : 0;
-  float sc[8], sh[8];
-  epilogue_coeffs(d, n0, col0 + vg * 8, sc, sh);
+  const int vr = lane >> 3, vg = lane & 7;
   const bool has_pre = d.r_pre != nullptr, has_post = d.r_post != nullptr, has_mask = EPI == 1 && d.mask != nullptr;
   const bool has_drop = EPI != 2 && d.drop != nullptr;
+  const bool res_is_pre = has_pre;                 // the prefetched residual: r_pre when present, else r_post
+  const bool post_in_step = has_pre && has_post;
+  const void* res_p = res_is_pre ? d.r_pre : d.r_post;
+  const size_t res_ld = res_is_pre ? d.ld_rpre : d.ld_rpost;
+  const bool has_res = has_pre || has_post;
+  int mrow[NB][2]; bool ok[NB][2];
+  uint4 qres[NB][2], qmk[NB][2];
 #pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    // operands of this step's two vectors first (their latency overlaps the scratch round trip)
-    size_t mrow[2]; bool ok[2];
-    float rpre[2][8], rpost[2][8], mk[2][8], dr[2][8];
+  for (int i = 0; i < NB; ++i)
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      const int m = mw0 + i * 16 + vr + 8 * t;
-      ok[t] = col_ok && m < a.M;
-      mrow[t] = ok[t] ? (a.perm ? (size_t)perm_decode(a, m).true_row : (size_t)m) : 0;
+      const int m = mw0 + (I0 + i) * 16 + vr + 8 * t;
+      ok[i][t] = col_ok && m < a.M;
+      mrow[i][t] = ok[i][t] ? (a.perm ? (int)perm_decode(a, m).true_row : m) : 0;
+      if (has_res) qres[i][t] = ldg16_bf16(res_p, (size_t)mrow[i][t] * res_ld + oc);
+      if (has_mask) qmk[i][t] = ldg16_bf16(d.mask, (size_t)mrow[i][t] * d.ld_mask + oc);
     }
-    if (has_pre) {
 #pragma unroll
-      for (int t = 0; t < 2; ++t) load8<DT>(d.r_pre, mrow[t] * d.ld_rpre + oc, rpre[t]);
-    }
-    if (has_post) {
+  for (int i = 0; i < NB; ++i) {
+    float rpost[2][8], dr[2][8];
+    if (post_in_step) {
 #pragma unroll
-      for (int t = 0; t < 2; ++t) load8<DT>(d.r_post, mrow[t] * d.ld_rpost + oc, rpost[t]);
-    }
-    if (has_mask) {
-#pragma unroll
-      for (int t = 0; t < 2; ++t) load8<DT>(d.mask, mrow[t] * d.ld_mask + oc, mk[t]);
+      for (int t = 0; t < 2; ++t) load8<DT>(d.r_post, (size_t)mrow[i][t] * d.ld_rpost + oc, rpost[t]);
     }
     if (has_drop) {
 #pragma unroll
-      for (int t = 0; t < 2; ++t) load8<WSEG_F32>(d.drop, (size_t)wseg_decode_row(d, (int)mrow[t]).n_glob * d.OC + oc, dr[t]);
+      for (int t = 0; t < 2; ++t) load8<WSEG_F32>(d.drop, (size_t)wseg_decode_row(d, mrow[i][t]).n_glob * d.OC + oc, dr[t]);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) wimg[(fk * 4 + e) * WLD + j * 16 + frow] = acc[i][j][e];   // C/D: col = lane&15, row = (lane>>4)*4 + reg
+      for (int e = 0; e < 4; ++e) wimg[(fk * 4 + e) * WLD + j * 16 + frow] = acc[I0 + i][j][e];   // C/D: col = lane&15, row = (lane>>4)*4 + reg
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-local: the scratch is written and read by this wave only
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -233,10 +239,16 @@ __device__ __forceinline__ void wave_local_epilogue(const Args& a, char* smem, i
 #pragma unroll
         for (int e = 0; e < 4; ++e) { v[e] = p0[e]; v[4 + e] = p1[e]; }
       }
-      const size_t m = mrow[t];
+      const size_t m = (size_t)mrow[i][t];
+      float res[8];
+      if (has_res) unpack8_bf16(qres[i][t], res);
       if (has_pre) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += rpre[t][e];
+        for (int e = 0; e < 8; ++e) v[e] += res[e];
+      }
+      if (!post_in_step && has_post) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) rpost[t][e] = res[e];
       }
       if constexpr (EPI == 0) {
         if (has_post) {
@@ -247,7 +259,7 @@ __device__ __forceinline__ void wave_local_epilogue(const Args& a, char* smem, i
 #pragma unroll
           for (int e = 0; e < 8; ++e) if (oc + e < d.relu_lt) v[e] = fmaxf(v[e], 0.f);
         }
-        if (d.out != nullptr && ok[t]) store8<DT>(d.out, m * d.ld_out + oc, v);
+        if (d.out != nullptr && ok[i][t]) store8<DT>(d.out, m * d.ld_out + oc, v);
         if (d.out2 != nullptr) {
           float o2[8];
 #pragma unroll
@@ -257,27 +269,47 @@ __device__ __forceinline__ void wave_local_epilogue(const Args& a, char* smem, i
             if (has_drop) x *= dr[t][e];
             o2[e] = x;
           }
-          if (ok[t]) store8<DT>(d.out2, m * d.ld_out2 + oc, o2);
+          if (ok[i][t]) store8<DT>(d.out2, m * d.ld_out2 + oc, o2);
         }
       } else if constexpr (EPI == 1) {
+        float mk[8];
+        if (has_mask) unpack8_bf16(qmk[i][t], mk);
         float o[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           float x = v[e] * sc[e];
           if (has_drop) x *= dr[t][e];
-          if (has_mask) x = mk[t][e] > 0.f ? x : 0.f;
+          if (has_mask) x = mk[e] > 0.f ? x : 0.f;
           if (has_post) x += rpost[t][e];
           o[e] = x;
         }
-        if (ok[t]) store8<DT>(d.out, m * d.ld_out + oc, o);
+        if (ok[i][t]) store8<DT>(d.out, m * d.ld_out + oc, o);
       } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-        if (ok[t]) store8<DT>(d.out, m * d.ld_out + oc, v);
+        if (ok[i][t]) store8<DT>(d.out, m * d.ld_out + oc, v);
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // scratch reads done before the next step overwrites it
   }
+}
+
+template <int EPI, int NI>
+__device__ __forceinline__ void wave_local_epilogue(const Args& a, char* smem, int wid, int lane, int mw0, int col0, int n0,
+                                                    const f32x4 (&acc)[NI][4]) {
+  const wseg_conv_desc& d = a.d;
+  constexpr int WLD = 64 + 4;                      // scratch row stride (floats): conflict-free for both access patterns
+  float* wimg = reinterpret_cast<float*>(smem) + wid * (16 * WLD);
+  const int vg = lane & 7;                         // this lane's vectors: rows vr and vr + 8 of the step, column group vg
+  const int oc_raw = n0 + col0 + vg * 8;
+  const bool col_ok = oc_raw < d.OC;
+  const int oc = col_ok ? oc_raw : 0;
+  float sc[8], sh[8];
+  epilogue_coeffs(d, n0, col0 + vg * 8, sc, sh);
+  constexpr int NB = 4;
+  wave_local_epilogue_batch<EPI, NI, 0, NB>(a, wimg, lane, mw0, oc, col_ok, sc, sh, acc);
+  if constexpr (NI > NB) wave_local_epilogue_batch<EPI, NI, NB, (NI - NB < NB ? NI - NB : NB)>(a, wimg, lane, mw0, oc, col_ok, sc, sh, acc);
+  static_assert(NI <= 2 * NB, "two batches cover the tile");
 }
 
 // BM = 128 (default) or 64 (few output pixels: twice the workgroups for the same work)
