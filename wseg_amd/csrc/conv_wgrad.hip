@@ -37,7 +37,7 @@ struct Args {
   int wave_epi;      // pipe kernel: 1 = wave-local atomic epilogue (WSEG_WGRAD_EPI)
   int stagger;       // 1 = ping-pong schedule of the pipe kernel (WSEG_WGRAD_STAGGER; off: its read slots — 24/8/16/0 transposed
                      //     reads + pixel addressing — are longer and less even than an MFMA slot, the stagger then costs time)
-  int diag;          // 0 = normal; timing diagnostics (WSEG_WGRAD_DIAG): 1 = no epilogue stores, 2 = plain stores
+  int diag;          // 0 = normal; timing diagnostics (WSEG_WGRAD_DIAG): 1 = no epilogue stores, 2 = plain stores, 4 / 5 = X / X and dY from the zero page
 };
 
 template <int DT, int BO, int BI, int WR, int WC>
@@ -367,6 +367,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pipe_kernel(const Args a) {
       if constexpr (UNIT) {
         const bool ok = xm[k] < m_end && (unsigned)(xoy[k] + dy) < (unsigned)OHs && (unsigned)(xox[k] + dx) < (unsigned)OWs;
         xrow[k] = ok ? xptr[k] : nullptr;
+        if (a.diag >= 4) xrow[k] = nullptr;          // timing diagnostics: X (4) / X and dY (5) from the zero page
         xptr[k] += xstep;
         if (d.OH2 != 0 && xm[k] < M1 && mn >= M1) {   // crosses into the second segment (rare): new coordinates, new tap shift
           const wseg_rowgeo rg = wseg_decode_row(d, min(mn, a.M - 1));
@@ -421,7 +422,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pipe_kernel(const Args a) {
     char* dst = smem + slot_off(buf, h) + wid * 1024;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-      const char* p = (my[k] < m_end && yok[k][h]) ? ybase[k] + h * 256 : zsrc;
+      const char* p = (my[k] < m_end && yok[k][h] && a.diag != 5) ? ybase[k] + h * 256 : zsrc;
       glds16(p, dst + k * 8192);
     }
     if (h == 1) {
