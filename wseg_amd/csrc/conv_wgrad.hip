@@ -351,38 +351,66 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pipe_kernel(const Args a) {
   if constexpr (UNIT) {
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-      const bool s2 = d.OH2 != 0 && xm[k] >= M1;
+      const bool s2 = d.OH2 != 0 && m_begin >= M1;   // the workgroup's FIRST segment (uniform); the switch adds xcross
       const long shift = (long)dy * (s2 ? d.IW2 : d.IW) + dx;
       xptr[k] = X + (((long)xm[k] + shift) * d.ld_x + ic0 + lc[k] * 8) * 2;
     }
   }
   const size_t xstep = (size_t)PK * d.ld_x * 2;
   const long xcross = (long)dy * (d.IW2 - d.IW) * d.ld_x * 2;      // pointer correction when a row enters segment 2
+  // UNIT: the K-tiles never straddle the boundary between the two row segments (views): the pixel range is walked as
+  // [m_begin, min(m_end, M1)) then [max(m_begin, M1), m_end), each in 64-row tiles (at most one tile more than a straight walk;
+  // rows past a sub-range's end read the zero page on both operands).  All geometry of a tile is then wave-uniform (scalars):
+  // per row there remain two bounds tests, the (oy, ox) advance and the source select — this loop is VALU-sensitive.
+  const int seg_end = d.OH2 != 0 ? M1 : a.M;
+  const int a_end = min(m_end, seg_end), b_begin = max(m_begin, seg_end);
+  const int nA = m_begin < a_end ? (a_end - m_begin + PK - 1) / PK : 0;
+  const int nB = m_end > b_begin ? (m_end - b_begin + PK - 1) / PK : 0;
+  int ty_idx = 0, tx_idx = 0;                        // index of the NEXT dY / X tile to issue
+  int y_m = m_begin, x_m = m_begin;                  // its first pixel row
+  int y_lim = nA > 0 ? a_end : m_end, x_lim = y_lim; // end of its sub-range
+  bool x_s2 = nA == 0 && d.OH2 != 0;                 // the X tile's segment
+  int rry[2][2], rrx[2][2];                          // row inside the tile per (k, h); huge where the channel half does not exist
+  bool xin[2] = {false, false};                      // the X tile being issued: tap lands inside the image
+  if constexpr (UNIT) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        rry[k][h] = yok[k][h] ? (tid >> 4) + 32 * k : 0x40000000;
+        rrx[k][h] = xok[k][h] ? (tid >> 4) + 32 * k : 0x40000000;
+      }
+  }
   auto x_prepare = [&]() {                           // call once per X tile, before its two half issues; advances to the next tile
+    if constexpr (UNIT) {
+      if (tx_idx == nA && nA > 0 && nB > 0) {        // (wave-uniform, once) enter the second segment: jump the pointers, decode afresh
+        const long jump = (long)(b_begin - x_m) * d.ld_x * 2 + xcross;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          xptr[k] += jump;
+          const wseg_rowgeo rg = wseg_decode_row(d, min(b_begin + (tid >> 4) + 32 * k, a.M - 1));
+          xoy[k] = rg.oy; xox[k] = rg.ox;
+        }
+        x_m = b_begin; x_lim = m_end; x_s2 = true;
+      }
+      const int OHs = x_s2 ? d.OH2 : d.OH, OWs = x_s2 ? d.OW2 : d.OW;
+      const int r64 = x_s2 ? a.r64_2 : a.r64_1, q64 = x_s2 ? a.q64_2 : a.q64_1;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        xin[k] = (unsigned)(xoy[k] + dy) < (unsigned)OHs && (unsigned)(xox[k] + dx) < (unsigned)OWs;
+        int ox = xox[k] + r64, oy = xoy[k] + q64;    // advance 64 rows (host guarantees one row wrap at most: simple_adv)
+        const bool cx = ox >= OWs;
+        ox = cx ? ox - OWs : ox; oy = cx ? oy + 1 : oy;
+        oy = oy >= OHs ? oy - OHs : oy;
+        xox[k] = ox; xoy[k] = oy;
+      }
+      return;
+    }
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const bool s2 = d.OH2 != 0 && xm[k] >= M1;
       const int OHs = s2 ? d.OH2 : d.OH, OWs = s2 ? d.OW2 : d.OW, IHs = s2 ? d.IH2 : d.IH, IWs = s2 ? d.IW2 : d.IW;
       const int mn = xm[k] + PK;
-      if constexpr (UNIT) {
-        const bool ok = xm[k] < m_end && (unsigned)(xoy[k] + dy) < (unsigned)OHs && (unsigned)(xox[k] + dx) < (unsigned)OWs;
-        xrow[k] = ok ? xptr[k] : nullptr;
-        if (a.diag >= 4) xrow[k] = nullptr;          // timing diagnostics: X (4) / X and dY (5) from the zero page
-        xptr[k] += xstep;
-        if (d.OH2 != 0 && xm[k] < M1 && mn >= M1) {   // crosses into the second segment (rare): new coordinates, new tap shift
-          const wseg_rowgeo rg = wseg_decode_row(d, min(mn, a.M - 1));
-          xoy[k] = rg.oy; xox[k] = rg.ox;
-          xptr[k] += xcross;
-        } else {                                     // branch-free (host guarantees one row wrap at most: simple_adv)
-          int ox = xox[k] + (s2 ? a.r64_2 : a.r64_1), oy = xoy[k] + (s2 ? a.q64_2 : a.q64_1);
-          const bool cx = ox >= OWs;
-          ox = cx ? ox - OWs : ox; oy = cx ? oy + 1 : oy;
-          oy = oy >= OHs ? oy - OHs : oy;
-          xox[k] = ox; xoy[k] = oy;
-        }
-        xm[k] = mn;
-        continue;
-      }
       xrow[k] = nullptr;
       if (xm[k] < m_end) {
         const int iy = xoy[k] * d.stride + ky * d.dil - d.pad;
@@ -412,6 +440,20 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pipe_kernel(const Args a) {
   };
   auto issue_x = [&](int h, int buf) {
     char* dst = smem + slot_off(buf, 2 + h) + wid * 1024;
+    if constexpr (UNIT) {
+      const int rem = a.diag >= 4 ? 0 : x_lim - x_m;  // rows of this tile inside its sub-range (diag: X from the zero page)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const char* p = (xin[k] && rrx[k][h] < rem) ? xptr[k] + h * 256 : zsrc;
+        glds16(p, dst + k * 8192);
+      }
+      if (h == 1) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) xptr[k] += xstep;
+        x_m += PK; ++tx_idx;
+      }
+      return;
+    }
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const char* p = (xrow[k] && xok[k][h]) ? xrow[k] + h * 256 : zsrc;
@@ -420,6 +462,26 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pipe_kernel(const Args a) {
   };
   auto issue_y = [&](int h, int buf) {               // half h of the NEXT Y tile; h == 1 advances to the following tile
     char* dst = smem + slot_off(buf, h) + wid * 1024;
+    if constexpr (UNIT) {
+      if (h == 0 && ty_idx == nA && nA > 0 && nB > 0) {   // (wave-uniform, once) enter the second segment
+        const long jump = (long)(b_begin - y_m) * d.ld_dy * 2;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) ybase[k] += jump;
+        y_m = b_begin; y_lim = m_end;
+      }
+      const int rem = a.diag == 5 ? 0 : y_lim - y_m;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const char* p = rry[k][h] < rem ? ybase[k] + h * 256 : zsrc;
+        glds16(p, dst + k * 8192);
+      }
+      if (h == 1) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) ybase[k] += ystep;
+        y_m += PK; ++ty_idx;
+      }
+      return;
+    }
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const char* p = (my[k] < m_end && yok[k][h] && a.diag != 5) ? ybase[k] + h * 256 : zsrc;
@@ -452,7 +514,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pipe_kernel(const Args a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int nt = (m_end - m_begin + PK - 1) / PK;
+  const int nt = UNIT ? nA + nB : (m_end - m_begin + PK - 1) / PK;
   // prologue: tile 0 entirely + the X halves of tile 1
   issue_y(0, 0); issue_y(1, 0);
   x_prepare(); issue_x(0, 0); issue_x(1, 0);
@@ -473,10 +535,10 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pipe_kernel(const Args a) {
       TR(VB[ks][h][j], bbase + rowoff[ks][h] + ((((wc & 1) * 4 + (HB) * 2 + j) ^ rsw[ks][h]) << 5));
 #define PACK_A()                                                                                                \
   _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int i = 0; i < 4; ++i)               \
-    _Pragma("unroll") for (int e = 0; e < 4; ++e) { af[ks][i][e] = va[ks][0][i][e]; af[ks][i][4 + e] = va[ks][1][i][e]; }
+    af[ks][i] = __builtin_shufflevector(va[ks][0][i], va[ks][1][i], 0, 1, 2, 3, 4, 5, 6, 7);
 #define PACK_B(BF, VB)                                                                                          \
   _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int j = 0; j < 2; ++j)               \
-    _Pragma("unroll") for (int e = 0; e < 4; ++e) { BF[ks][j][e] = VB[ks][0][j][e]; BF[ks][j][4 + e] = VB[ks][1][j][e]; }
+    BF[ks][j] = __builtin_shufflevector(VB[ks][0][j], VB[ks][1][j], 0, 1, 2, 3, 4, 5, 6, 7);
 #define WAIT_LDS() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define MFMA_Q(HA, HB, BF)                                                                                      \
   do {                                                                                                          \
