@@ -299,3 +299,36 @@ def test_batched_transposed_pack_bf16_matches_f32_source():
     o, t, i = layers[0]
     ref = mirror[:o * t * i].view(o, t, i).permute(2, 1, 0).contiguous().view(-1)
     assert torch.equal(b[:o * t * i], ref)
+
+
+@pytest.mark.parametrize("bm,IC2", [(0, 192), (224, 192), (0, 64), (0, 448)])
+def test_conv_two_sources(bm, IC2):
+    """Two-source 1x1 (K-concatenation of a bottleneck's skip conv and last conv): out = in . W[:,0,:] + in2 . W[:,1,:] with the
+    fused BN-ReLU-dropout second output, two row segments, against the two separate convolutions on the CPU."""
+    from wseg_amd import _lib as L
+    tdt = torch.bfloat16
+    N, IC, OC = 2, 192, 512
+    (H1, W1), (H2, W2) = (21, 17), (8, 9)
+    xs = [[_rand((N, c, h, w), 1 + 2 * s_ + v).to(tdt).float() for (h, w) in ((H1, W1), (H2, W2))] for v, s_, c in ((0, 0, IC), (1, 5, IC2))]
+    w1 = _rand((OC, IC, 1, 1), 30, (1.0 / IC) ** 0.5).to(tdt).float()
+    w2 = _rand((OC, IC2, 1, 1), 31, (1.0 / IC2) ** 0.5).to(tdt).float()
+    scale, shift = _rand((OC,), 6) + 1.5, _rand((OC,), 7)
+    drop = (torch.rand(2 * N, OC, generator=torch.Generator().manual_seed(8)) > 0.5).float() * 2
+    rows = lambda t: _nhwc(t).reshape(-1, t.shape[1])
+    ref = torch.cat([rows(F.conv2d(a, w1) + F.conv2d(b, w2)) for a, b in zip(xs[0], xs[1])])
+    img = torch.cat([torch.arange(N).repeat_interleave(H1 * W1), N + torch.arange(N).repeat_interleave(H2 * W2)])
+    act = F.relu(ref * scale + shift) * drop[img]
+    dev = "cuda"
+    a = torch.cat([rows(t) for t in xs[0]]).to(dev, tdt)
+    b = torch.zeros(a.shape[0], IC2 + 64, device=dev, dtype=tdt)         # second source with a row stride
+    b[:, :IC2] = torch.cat([rows(t) for t in xs[1]]).to(dev, tdt)
+    wcat = torch.cat([w1.reshape(OC, 1, IC), w2.reshape(OC, 1, IC2)], dim=2).contiguous().to(dev, tdt)   # rows [W1[oc] | W2[oc]]
+    out = torch.full((a.shape[0], OC), float("nan"), device=dev, dtype=tdt)
+    out2 = torch.full_like(out, float("nan"))
+    L.conv_igemm(a, wcat, out, out2, N=N, IH=H1, IW=W1, IC=IC, OH=H1, OW=W1, OC=OC, KH=1, KW=1, seg2=(H2, W2, H2, W2),
+                 in2=b, IC2=IC2, ld_in2=IC2 + 64, scale=scale.to(dev), shift=shift.to(dev), drop=drop.to(dev), bm_hint=bm)
+    tol = dict(rtol=2e-2, atol=2e-2)
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), **tol)
+    np.testing.assert_allclose(out2.float().cpu().numpy(), act.numpy(), rtol=2e-2, atol=4e-2)
+    with pytest.raises(RuntimeError):                                    # only the 1x1 forward form exists
+        L.conv_igemm(a, wcat, out, N=N, IH=H1, IW=W1, IC=IC, OH=H1, OW=W1, OC=OC, KH=3, KW=3, pad=1, seg2=(H2, W2, H2, W2), in2=b, IC2=IC2, ld_in2=IC2 + 64)

@@ -43,7 +43,8 @@ class ConvDesc(C.Structure):
                 ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("dil", C.c_int32), ("pad", C.c_int32),
                 ("mode", C.c_int32), ("epi", C.c_int32), ("dtype", C.c_int32), ("relu_out2", C.c_int32),
                 ("relu_lt", C.c_int32), ("bm_hint", C.c_int32),
-                ("IH2", C.c_int32), ("IW2", C.c_int32), ("OH2", C.c_int32), ("OW2", C.c_int32)]
+                ("IH2", C.c_int32), ("IW2", C.c_int32), ("OH2", C.c_int32), ("OW2", C.c_int32),
+                ("in2", C.c_void_p), ("ld_in2", C.c_int32), ("IC2", C.c_int32)]
 
 
 class WgradDesc(C.Structure):
@@ -94,7 +95,7 @@ def dtype_code(t):
 def conv_igemm(inp, w, out=None, out2=None, *, N, IH, IW, IC, OH, OW, OC, KH, KW, stride=1, dil=1, pad=0,
                mode=0, epi=0, r_pre=None, r_post=None, mask=None, scale=None, shift=None, drop=None,
                ld_in=None, ld_out=None, ld_out2=None, ld_rpre=None, ld_rpost=None, ld_mask=None, relu_out2=1,
-               relu_lt=0, bm_hint=0, seg2=None):
+               relu_lt=0, bm_hint=0, seg2=None, in2=None, ld_in2=None, IC2=0):
     d = ConvDesc()
     d.inp, d.w, d.out, d.out2 = _ptr(inp), _ptr(w), _ptr(out), _ptr(out2)
     d.r_pre, d.r_post, d.mask = _ptr(r_pre), _ptr(r_post), _ptr(mask)
@@ -106,6 +107,8 @@ def conv_igemm(inp, w, out=None, out2=None, *, N, IH, IW, IC, OH, OW, OC, KH, KW
     d.mode, d.epi, d.dtype, d.relu_out2, d.relu_lt, d.bm_hint = mode, epi, dtype_code(inp), relu_out2, relu_lt, bm_hint
     if seg2 is not None:                         # (IH2, IW2, OH2, OW2): second row segment, same N
         d.IH2, d.IW2, d.OH2, d.OW2 = seg2
+    if in2 is not None:                          # two-source 1x1 (w = [OC][2][IC])
+        d.in2, d.IC2, d.ld_in2 = _ptr(in2), IC2, ld_in2 or (IC2 or IC)
     sampled, launch_idx = _profile_sample() if PROFILE is not None else (False, 0)
     if sampled:                                  # bench.py: HIP events on the launch stream around this launch
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -116,8 +119,9 @@ def conv_igemm(inp, w, out=None, out2=None, *, N, IH, IW, IC, OH, OW, OC, KH, KW
         pix = N * (OH * OW if mode == 0 else IH * IW)        # algorithmic: the conv's output pixels
         if seg2 is not None:
             pix += N * (seg2[2] * seg2[3] if mode == 0 else seg2[0] * seg2[1])
-        PROFILE.append((ev0, ev1, 2.0 * pix * IC * OC * KH * KW,
-                        f"{'fwd' if mode == 0 else 'dgrad'} {IC}->{OC} k{KH} s{stride} d{dil} {OH}x{OW}", launch_idx))
+        kin = IC * KH * KW + ((IC2 or IC) if in2 is not None else 0)
+        PROFILE.append((ev0, ev1, 2.0 * pix * kin * OC,
+                        f"{'fwd' if mode == 0 else 'dgrad'} {IC}{('+%d' % (IC2 or IC)) if in2 is not None else ''}->{OC} k{KH} s{stride} d{dil} {OH}x{OW}", launch_idx))
 
 
 def conv_wgrad(x, dy, dw, *, N, IH, IW, IC, OH, OW, OC, KH, KW, stride=1, dil=1, pad=0,

@@ -25,6 +25,8 @@ struct Args {
   int M;            // N*OH*OW
   int taps;         // KH*KW
   int cpt;          // K-steps per tap = IC*ES/128
+  int cpt2;         // two-source 1x1: K-steps of the second source (= IC2*ES/128)
+  int krow;         // K elements per weight row (taps*IC, or IC + IC2)
   int ntn;          // column tiles
   int nwg;
   int row0;         // first output row (pixel) of this launch (a launch may cover a row sub-range)
@@ -546,10 +548,10 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const Args a) {
       if (ntaps == 0) { tl = 0ull; ntaps = 1; }    // (a class without taps: one all-padding tap keeps the pipeline uniform)
     }
   }
-  const char* bptr0 = Wp + ((size_t)(n0 + r0) * a.taps * d.IC + (size_t)lc * CH) * ES;   // OC % 256 == 0 (host-checked)
+  const char* bptr0 = Wp + ((size_t)(n0 + r0) * a.krow + (size_t)lc * CH) * ES;   // OC % 256 == 0 (host-checked)
   const char* bptr = bptr0 + (size_t)(tl & 15ull) * d.IC * ES;
   int b_ti = 0, b_cc = 0;                          // (perm only) position of the NEXT B tile in the tap list
-  const int brs = 64 * a.taps * d.IC * ES;         // bytes between B rows r0 + 64*j
+  const int brs = 64 * a.krow * ES;                // bytes between B rows r0 + 64*j
   auto issue_b = [&](int h, int buf) {
     char* dst = smem + buf * TILE256 + (2 + h) * HALF256 + wid * 1024;
     glds16(bptr + (2 * h) * brs, dst);
@@ -562,7 +564,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const Args a) {
 
   // The weight tiles need no pixel geometry: their LDS-DMA is issued BEFORE the row decode (three integer divisions per row)
   // and the tap set-up, which then run in the shadow of the DMA latency instead of in front of it.
-  const int nt = ntaps * a.cpt;
+  const int nt = d.in2 != nullptr ? a.cpt + a.cpt2 : ntaps * a.cpt;
   if (a.early_b) {
     issue_b(0, 0); issue_b(1, 0); advance_b();
     if (nt > 1) { issue_b(0, 1); issue_b(1, 1); advance_b(); }
@@ -586,7 +588,10 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const Args a) {
   const char* aptr[4];
   unsigned a_live = 0;                             // bit j: row j reads real data (pointer advances by 128 B per K-tile)
   auto set_tap = [&](int tap) {
-    const int ky = tap / d.KW, kx = tap - ky * d.KW;
+    const bool src2 = d.in2 != nullptr && tap == 1;   // two-source 1x1: "tap" 1 = the same pixel of the second input
+    const int ky = d.in2 != nullptr ? 0 : tap / d.KW, kx = d.in2 != nullptr ? 0 : tap - ky * d.KW;
+    const char* INs = src2 ? reinterpret_cast<const char*>(d.in2) + lc * 16 : INl;
+    const int lds = src2 ? d.ld_in2 : d.ld_in;
     a_live = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -603,7 +608,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const Args a) {
         else { iy = ty / d.stride; ix = tx / d.stride; ok = ok && (iy * d.stride == ty) && (ix * d.stride == tx); }
       }
       ok = ok && iy >= 0 && iy < H && ix >= 0 && ix < W;
-      if (ok) { aptr[j] = INl + (size_t)(a_base[j] + iy * W + ix) * d.ld_in * ES; a_live |= 1u << j; }
+      if (ok) { aptr[j] = INs + (size_t)(a_base[j] + iy * W + ix) * lds * ES; a_live |= 1u << j; }
       else    { aptr[j] = zsrc; }
     }
   };
@@ -616,7 +621,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const Args a) {
   auto advance_a = [&]() {
 #pragma unroll
     for (int j = 0; j < 4; ++j) aptr[j] += ((a_live >> j) & 1u) << 7;
-    if (++a_cc == a.cpt) { a_cc = 0; if (++a_tap < ntaps) set_tap((int)((tl >> (4 * a_tap)) & 15ull)); }
+    if (++a_cc == a.cpt) { a_cc = 0; if (++a_tap < ntaps) set_tap((int)((tl >> (4 * a_tap)) & 15ull)); }   // (two sources: the walk ends after cpt2 steps of source 2)
   };
   f32x4 acc[NI][4];
 #pragma unroll
@@ -1113,7 +1118,17 @@ extern "C" int wseg_conv_igemm(const wseg_conv_desc* d, void* stream) {
   a.early_b = early_b;
   a.M = (int)M;
   a.taps = d->KH * d->KW;
+  if (d->in2) {                                    // two-source 1x1: the second source is "tap" 1 of w = [OC][2][IC]
+    WSEG_CHECK(d->KH == 1 && d->KW == 1 && d->stride == 1 && d->mode == 0 && d->pad == 0 && d->dtype == WSEG_BF16 && d->OC % 256 == 0 &&
+               d->ld_in2 % 8 == 0 && (d->bm_hint == 0 || d->bm_hint == 256 || d->bm_hint == 224),
+               "conv_igemm: the two-source form is a bf16 forward 1x1 with OC %% 256 == 0 on the 256-tile kernel");
+    a.taps = 2;
+  }
   a.cpt = d->IC * es / ROWB;
+  const int ic2 = d->in2 ? (d->IC2 > 0 ? d->IC2 : d->IC) : 0;
+  WSEG_CHECK(!d->in2 || ((ic2 * es) % ROWB == 0 && d->ld_in2 >= ic2), "conv_igemm: IC2=%d must be a multiple of %d and <= ld_in2", ic2, ROWB / es);
+  a.cpt2 = ic2 * es / ROWB;
+  a.krow = d->in2 ? d->IC + ic2 : a.taps * d->IC;
   a.ntn = (d->OC + BN - 1) / BN;
   // few output pixels (view 2, 16x16 maps): 64-row tiles double the workgroup count
   const bool small = d->bm_hint == 64 || (d->bm_hint != 128 && ((M + 127) / 128) * a.ntn < 384 && M > 64);
@@ -1136,7 +1151,7 @@ extern "C" int wseg_conv_igemm(const wseg_conv_desc* d, void* stream) {
     const long rounds = (t256 + 255) / 256;
     static const int auto256 = getenv("WSEG_CONV256") ? atoi(getenv("WSEG_CONV256")) : 1;   // (0: A/B switch)
     static const int split_tail = getenv("WSEG_CONV_SPLIT") ? atoi(getenv("WSEG_CONV_SPLIT")) : 0;
-    big = d->bm_hint == 256 || d->bm_hint == 257 || d->bm_hint == 224 ||
+    big = d->bm_hint == 256 || d->bm_hint == 257 || d->bm_hint == 224 || d->in2 != nullptr ||
           (auto256 && ((t256 >= 200 && (double)t256 / (double)(rounds * 256) >= 0.80) || (split_tail && d->bm_hint == 0 && t256 >= 256)));
     if (big)
       WSEG_CHECK(d->IH <= 16384 && d->IW <= 16384 && d->OH <= 16384 && d->OW <= 16384 && d->pad <= 4096 &&

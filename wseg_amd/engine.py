@@ -17,6 +17,7 @@ from . import arch
 from . import _lib as L
 
 HEAD_LD = int(os.environ.get("WSEG_HEAD_LD", "192"))   # fused head rows: [f_proj 128 | cam 21 | zero pad]  (256: the head GEMMs take the 256-tile kernels)
+FUSE_SKIP = os.environ.get("WSEG_FUSE_SKIP", "1") != "0"   # bottleneck skip conv + last conv as one two-source launch (bf16)
 FEAT_LD = 256          # PCM feature rows: [f8_3 64 | f8_4 128 | x_s 3 | zero pad 61]
 
 
@@ -214,6 +215,14 @@ class Engine:
                 P["w"][cname] = mirror[off:off + n].view(co, T, ci)
                 if cname not in no_dgrad:
                     P["wt"][cname] = self.flat_wt[off:off + n].view(ci, T, co)
+        # bottleneck blocks (b6, b7), bf16 mode: skip conv and last conv as ONE two-source product (K-concatenation):
+        # rows [W_branch1[oc] | W_branch2b2[oc]] — the skip output is then neither written nor re-read (444 MB each way for b7)
+        if dt == L.BF16 and FUSE_SKIP:
+            for b in arch.BLOCKS:
+                if b[1] != "res" and b[0] not in arch.FROZEN_BLOCKS and b[2] == b[4] // 2 and b[5] == 1 and b[4] % 256 == 0:
+                    P["w"][b[0] + ".skip_fused"] = torch.cat([P["w"][b[0] + ".conv_branch1"], P["w"][b[0] + ".conv_branch2b2"]], dim=1)
+                    # backward twin: d_t = D . W_branch1 + du1 . W_branch2a  (transposed packs [cin][1][cout] | [cin][1][cout/4])
+                    P["wt"][b[0] + ".skip_fused"] = torch.cat([P["wt"][b[0] + ".conv_branch1"], P["wt"][b[0] + ".conv_branch2a"]], dim=2)
         # fused head: rows [fc_proj | fc8 | 0]; its transposed pack is made from the two f32 masters directly
         wh = torch.zeros(HEAD_LD, 1, 4096, device=device, dtype=tdt)
         wht = torch.zeros(4096, 1, HEAD_LD, device=device, dtype=tdt)
@@ -352,11 +361,14 @@ class Engine:
                 conv(t, name + ".conv_branch2a", None, v1, cin, c4, 1, stride, 1, dims, odims, scale=s1, shift=sh1, drop=d1)
                 v2 = E(Mo, c2)
                 conv(v1, name + ".conv_branch2b1", None, v2, c4, c2, 3, 1, d, odims, odims, scale=s2, shift=sh2, drop=d2)
-                b1 = E(Mo, cout)
-                conv(t, name + ".conv_branch1", b1, None, cin, cout, 1, stride, 1, dims, odims)
                 xn = None
                 tn = E(Mo, cout)
-                conv(v2, name + ".conv_branch2b2", xn, tn, c2, cout, 1, 1, 1, odims, odims, r_post=b1, scale=nsc, shift=nsh, drop=ndrop)
+                if (name + ".skip_fused") in P["w"]:            # out = [t | v2] . [W_branch1 | W_branch2b2]^T in one launch
+                    conv(t, name + ".skip_fused", xn, tn, cin, cout, 1, 1, 1, odims, odims, in2=v2, scale=nsc, shift=nsh, drop=ndrop)
+                else:
+                    b1 = E(Mo, cout)
+                    conv(t, name + ".conv_branch1", b1, None, cin, cout, 1, stride, 1, dims, odims)
+                    conv(v2, name + ".conv_branch2b2", xn, tn, c2, cout, 1, 1, 1, odims, odims, r_post=b1, scale=nsc, shift=nsh, drop=ndrop)
                 if save:
                     S[name] = dict(t=t, v1=v1, v2=v2)
             S["dims"][name] = (dims, odims)
@@ -592,10 +604,15 @@ class Engine:
                 wgrad(name + ".conv_branch2b1", sv["v1"], du2, c4, c2, 3, 1, d, dout, dout)
                 wgrad(name + ".conv_branch1", sv["t"], D, cin, cout, 1, stride, 1, din, dout)
                 wgrad(name + ".conv_branch2a", sv["t"], du1, cin, c4, 1, stride, 1, din, dout)
-                tmp = E(Mi, cin)
-                dgrad(D, name + ".conv_branch1", tmp, cin, cout, 1, stride, 1, din, dout)
                 Din = E(Mi, cin)
-                dgrad(du1, name + ".conv_branch2a", Din, cin, c4, 1, stride, 1, din, dout, epi=1, scale=sa, mask=sv["t"], r_pre=tmp)
+                if (name + ".skip_fused") in P["wt"]:          # both 1x1 data gradients into t as ONE two-source product
+                    seg2 = (dout[1][0], dout[1][1], din[1][0], din[1][1]) if V == 2 else None
+                    L.conv_igemm(D, P["wt"][name + ".skip_fused"], Din, None, N=N, IH=dout[0][0], IW=dout[0][1], IC=cout, OH=din[0][0], OW=din[0][1],
+                                 OC=cin, KH=1, KW=1, in2=du1, IC2=c4, epi=1, scale=sa, mask=sv["t"], seg2=seg2)
+                else:
+                    tmp = E(Mi, cin)
+                    dgrad(D, name + ".conv_branch1", tmp, cin, cout, 1, stride, 1, din, dout)
+                    dgrad(du1, name + ".conv_branch2a", Din, cin, c4, 1, stride, 1, din, dout, epi=1, scale=sa, mask=sv["t"], r_pre=tmp)
                 D = Din
                 if self.block_done_hook is not None:
                     self.block_done_hook(name)
