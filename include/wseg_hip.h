@@ -67,10 +67,11 @@ typedef struct wseg_conv_desc {
    * [0, N*OH*OW) use (IH,IW,OH,OW); rows beyond use (IH2,IW2,OH2,OW2), same N, their input pixels follow the
    * first segment's N*IH*IW rows; drop then has 2N rows.  OH2 == 0: single segment. */
   int32_t IH2, IW2, OH2, OW2;
-  /* optional SECOND INPUT of a 1x1 convolution (K-concatenation): out = in . W[:, :IC] + in2 . W[:, IC:] with w = [OC][IC + IC2] —
-   * a bottleneck block's skip conv and its last conv (network/resnet38d.py:83-97: branch1 + branch2) as ONE product, so the skip
-   * output is neither written nor re-read; with the transposed packs the same form is the sum of two 1x1 data gradients.
-   * mode 0, KH = KW = 1, stride 1, pad 0, bf16, OC % 256 == 0, IC2 % 64 == 0 (0: IC2 = IC); NULL: none. */
+  /* optional SECOND INPUT (K-concatenation): out = conv(in; W[:, :KH*KW*IC]) + in2 . W[:, KH*KW*IC:] with w = [OC][KH*KW*IC + IC2] —
+   * a residual block's last conv and its 1x1 skip conv (network/resnet38d.py:35-47, 83-97: branch1 + branch2) as ONE product: the
+   * second source is one extra K segment read at the output pixel itself, so the skip output is neither written nor re-read.  With
+   * the transposed packs and mode 1 the same form is the sum of the two data gradients into the block's input.  Same-size stride-1
+   * convolution (pad = dil*(KH/2)), bf16, OC % 256 == 0, IC2 % 64 == 0 (0: IC2 = IC), in2 on the OUTPUT pixel grid; NULL: none. */
   const void* in2;
   int32_t ld_in2, IC2;
 } wseg_conv_desc;

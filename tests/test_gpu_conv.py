@@ -330,5 +330,40 @@ def test_conv_two_sources(bm, IC2):
     tol = dict(rtol=2e-2, atol=2e-2)
     np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), **tol)
     np.testing.assert_allclose(out2.float().cpu().numpy(), act.numpy(), rtol=2e-2, atol=4e-2)
-    with pytest.raises(RuntimeError):                                    # only the 1x1 forward form exists
-        L.conv_igemm(a, wcat, out, N=N, IH=H1, IW=W1, IC=IC, OH=H1, OW=W1, OC=OC, KH=3, KW=3, pad=1, seg2=(H2, W2, H2, W2), in2=b, IC2=IC2, ld_in2=IC2 + 64)
+    with pytest.raises(RuntimeError):                                    # only same-size stride-1 forms exist (rejected before any launch)
+        L.conv_igemm(a, wcat, out, N=N, IH=H1, IW=W1, IC=IC, OH=(H1 + 1) // 2, OW=(W1 + 1) // 2, OC=OC, KH=1, KW=1, stride=2,
+                     seg2=(H2, W2, (H2 + 1) // 2, (W2 + 1) // 2), in2=b, IC2=IC2, ld_in2=IC2 + 64)
+
+
+@pytest.mark.parametrize("dil,IC2", [(1, 128), (2, 320)])
+def test_conv_two_sources_3x3(dil, IC2):
+    """Residual-block form of the two-source product: a same-size 3x3 (dilated) convolution plus a 1x1 on a second input, forward
+    (mode 0) and as the sum of the two data gradients (mode 1 on the transposed packs), two row segments."""
+    from wseg_amd import _lib as L
+    tdt = torch.bfloat16
+    N, IC, OC, k = 2, 128, 256, 3
+    (H1, W1), (H2, W2) = (19, 16), (7, 10)
+    pad = dil
+    x1 = [_rand((N, IC, h, w), 1 + i).to(tdt).float() for i, (h, w) in enumerate(((H1, W1), (H2, W2)))]
+    x2 = [_rand((N, IC2, h, w), 11 + i).to(tdt).float() for i, (h, w) in enumerate(((H1, W1), (H2, W2)))]
+    w1 = _rand((OC, IC, k, k), 30, (1.0 / (9 * IC)) ** 0.5).to(tdt).float()
+    w2 = _rand((OC, IC2, 1, 1), 31, (1.0 / IC2) ** 0.5).to(tdt).float()
+    rows = lambda t: _nhwc(t).reshape(-1, t.shape[1])
+    ref = torch.cat([rows(F.conv2d(a, w1, None, 1, pad, dil) + F.conv2d(b, w2)) for a, b in zip(x1, x2)])
+    dev = "cuda"
+    a = torch.cat([rows(t) for t in x1]).to(dev, tdt)
+    b = torch.cat([rows(t) for t in x2]).to(dev, tdt)
+    wcat = torch.cat([w1.permute(0, 2, 3, 1).reshape(OC, 9 * IC), w2.reshape(OC, IC2)], dim=1).contiguous().to(dev, tdt)
+    out = torch.full((a.shape[0], OC), float("nan"), device=dev, dtype=tdt)
+    L.conv_igemm(a, wcat, out, N=N, IH=H1, IW=W1, IC=IC, OH=H1, OW=W1, OC=OC, KH=k, KW=k, dil=dil, pad=pad, seg2=(H2, W2, H2, W2), in2=b, IC2=IC2)
+    tol = dict(rtol=2e-2, atol=2e-2)
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), **tol)
+    # mode 1: dX = dgrad_3x3(dY1; V1) + dY2 . V2 for convolutions V1 [OCv][IC_v][3][3] (input = this test's output side) and V2 1x1
+    OCv = IC                                           # dY1 has OCv channels, dX has OC channels
+    v1 = _rand((OCv, OC, k, k), 40, (1.0 / (9 * OCv)) ** 0.5).to(tdt).float()     # conv OC -> OCv
+    v2 = _rand((IC2, OC, 1, 1), 41, (1.0 / IC2) ** 0.5).to(tdt).float()           # conv OC -> IC2
+    refd = torch.cat([rows(F.conv_transpose2d(dy1, v1, None, 1, pad, 0, 1, dil) + F.conv_transpose2d(dy2, v2)) for dy1, dy2 in zip(x1, x2)])
+    wt = torch.cat([v1.permute(1, 2, 3, 0).reshape(OC, 9 * OCv), v2.reshape(IC2, OC).t()], dim=1).contiguous().to(dev, tdt)   # [OC][9*OCv + IC2]
+    dx = torch.full((a.shape[0], OC), float("nan"), device=dev, dtype=tdt)
+    L.conv_igemm(a, wt, dx, N=N, IH=H1, IW=W1, IC=OCv, OH=H1, OW=W1, OC=OC, KH=k, KW=k, dil=dil, pad=pad, mode=1, seg2=(H2, W2, H2, W2), in2=b, IC2=IC2)
+    np.testing.assert_allclose(dx.float().cpu().numpy(), refd.numpy(), **tol)

@@ -107,8 +107,11 @@ def conv_igemm(inp, w, out=None, out2=None, *, N, IH, IW, IC, OH, OW, OC, KH, KW
     d.mode, d.epi, d.dtype, d.relu_out2, d.relu_lt, d.bm_hint = mode, epi, dtype_code(inp), relu_out2, relu_lt, bm_hint
     if seg2 is not None:                         # (IH2, IW2, OH2, OW2): second row segment, same N
         d.IH2, d.IW2, d.OH2, d.OW2 = seg2
-    if in2 is not None:                          # two-source 1x1 (w = [OC][2][IC])
+    if in2 is not None:                          # two sources: w = [OC][KH*KW*IC + IC2]
         d.in2, d.IC2, d.ld_in2 = _ptr(in2), IC2, ld_in2 or (IC2 or IC)
+    krow = KH * KW * IC + ((IC2 or IC) if in2 is not None else 0)
+    if w.numel() < OC * krow:                    # (raw pointers beyond this line: a short weight buffer would be read out of bounds)
+        raise RuntimeError(f"conv_igemm: weight buffer has {w.numel()} elements, the launch reads {OC} x {krow}")
     sampled, launch_idx = _profile_sample() if PROFILE is not None else (False, 0)
     if sampled:                                  # bench.py: HIP events on the launch stream around this launch
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

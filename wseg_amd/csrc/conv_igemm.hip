@@ -534,7 +534,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const Args a) {
   const char* zsrc = zero + pch * 16;
   const char* INl = IN + lc * 16;
   // tap list (4-bit entries): all taps, or — parity-permuted rows, tile inside one class — only the class's valid taps
-  unsigned long long tl = 0x876543210ull;
+  unsigned long long tl = 0xFEDCBA9876543210ull;
   int ntaps = a.taps;
   if (a.perm) {
     const int c0 = perm_decode(a, m0).cls, c1 = perm_decode(a, min(m0 + BMT - 1, a.M - 1)).cls;
@@ -564,7 +564,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const Args a) {
 
   // The weight tiles need no pixel geometry: their LDS-DMA is issued BEFORE the row decode (three integer divisions per row)
   // and the tap set-up, which then run in the shadow of the DMA latency instead of in front of it.
-  const int nt = d.in2 != nullptr ? a.cpt + a.cpt2 : ntaps * a.cpt;
+  const int nt = d.in2 != nullptr ? (ntaps - 1) * a.cpt + a.cpt2 : ntaps * a.cpt;
   if (a.early_b) {
     issue_b(0, 0); issue_b(1, 0); advance_b();
     if (nt > 1) { issue_b(0, 1); issue_b(1, 1); advance_b(); }
@@ -588,8 +588,9 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const Args a) {
   const char* aptr[4];
   unsigned a_live = 0;                             // bit j: row j reads real data (pointer advances by 128 B per K-tile)
   auto set_tap = [&](int tap) {
-    const bool src2 = d.in2 != nullptr && tap == 1;   // two-source 1x1: "tap" 1 = the same pixel of the second input
-    const int ky = d.in2 != nullptr ? 0 : tap / d.KW, kx = d.in2 != nullptr ? 0 : tap - ky * d.KW;
+    const bool src2 = d.in2 != nullptr && tap == d.KH * d.KW;   // two sources: the extra last "tap" = the output pixel itself in the second input
+    const int tg = src2 ? (d.KH / 2) * d.KW + d.KW / 2 : tap;    // (its geometry is the centre tap's: same-size convolution, stride 1)
+    const int ky = tg / d.KW, kx = tg - ky * d.KW;
     const char* INs = src2 ? reinterpret_cast<const char*>(d.in2) + lc * 16 : INl;
     const int lds = src2 ? d.ld_in2 : d.ld_in;
     a_live = 0;
@@ -1118,17 +1119,17 @@ extern "C" int wseg_conv_igemm(const wseg_conv_desc* d, void* stream) {
   a.early_b = early_b;
   a.M = (int)M;
   a.taps = d->KH * d->KW;
-  if (d->in2) {                                    // two-source 1x1: the second source is "tap" 1 of w = [OC][2][IC]
-    WSEG_CHECK(d->KH == 1 && d->KW == 1 && d->stride == 1 && d->mode == 0 && d->pad == 0 && d->dtype == WSEG_BF16 && d->OC % 256 == 0 &&
-               d->ld_in2 % 8 == 0 && (d->bm_hint == 0 || d->bm_hint == 256 || d->bm_hint == 224),
-               "conv_igemm: the two-source form is a bf16 forward 1x1 with OC %% 256 == 0 on the 256-tile kernel");
-    a.taps = 2;
+  if (d->in2) {                                    // two sources: the second one is an extra last "tap" of w = [OC][KH*KW*IC + IC2]
+    WSEG_CHECK(d->KH == d->KW && (d->KH & 1) && d->KH * d->KW < 15 && d->stride == 1 && d->pad == d->dil * (d->KH / 2) &&
+               d->dtype == WSEG_BF16 && d->OC % 256 == 0 && d->ld_in2 % 8 == 0 && (d->bm_hint == 0 || d->bm_hint == 256 || d->bm_hint == 224),
+               "conv_igemm: the two-source form is a same-size stride-1 bf16 convolution with OC %% 256 == 0 on the 256-tile kernel");
+    a.taps = d->KH * d->KW + 1;
   }
   a.cpt = d->IC * es / ROWB;
   const int ic2 = d->in2 ? (d->IC2 > 0 ? d->IC2 : d->IC) : 0;
   WSEG_CHECK(!d->in2 || ((ic2 * es) % ROWB == 0 && d->ld_in2 >= ic2), "conv_igemm: IC2=%d must be a multiple of %d and <= ld_in2", ic2, ROWB / es);
   a.cpt2 = ic2 * es / ROWB;
-  a.krow = d->in2 ? d->IC + ic2 : a.taps * d->IC;
+  a.krow = d->in2 ? d->KH * d->KW * d->IC + ic2 : a.taps * d->IC;
   a.ntn = (d->OC + BN - 1) / BN;
   // few output pixels (view 2, 16x16 maps): 64-row tiles double the workgroup count
   const bool small = d->bm_hint == 64 || (d->bm_hint != 128 && ((M + 127) / 128) * a.ntn < 384 && M > 64);

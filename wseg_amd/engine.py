@@ -218,6 +218,13 @@ class Engine:
         # bottleneck blocks (b6, b7), bf16 mode: skip conv and last conv as ONE two-source product (K-concatenation):
         # rows [W_branch1[oc] | W_branch2b2[oc]] — the skip output is then neither written nor re-read (444 MB each way for b7)
         if dt == L.BF16 and FUSE_SKIP:
+            for b in arch.BLOCKS:                               # (b5: the residual-block form — 3x3 last conv + 1x1 skip conv at stride 1)
+                if b[1] == "res" and b[0] not in arch.FROZEN_BLOCKS and not arch.block_same_shape(b) and b[5] == 1 and b[4] % 256 == 0 and b[2] % 256 == 0:
+                    nm, cin_, mid_, cout_ = b[0], b[2], b[3], b[4]
+                    P["w"][nm + ".skip_fused"] = torch.cat([P["w"][nm + ".conv_branch2b1"].reshape(cout_, 9 * mid_),
+                                                             P["w"][nm + ".conv_branch1"].reshape(cout_, cin_)], dim=1)
+                    P["wt"][nm + ".skip_fused"] = torch.cat([P["wt"][nm + ".conv_branch2a"].reshape(cin_, 9 * mid_),
+                                                              P["wt"][nm + ".conv_branch1"].reshape(cin_, cout_)], dim=1)
             for b in arch.BLOCKS:
                 if b[1] != "res" and b[0] not in arch.FROZEN_BLOCKS and b[2] == b[4] // 2 and b[5] == 1 and b[4] % 256 == 0:
                     P["w"][b[0] + ".skip_fused"] = torch.cat([P["w"][b[0] + ".conv_branch1"], P["w"][b[0] + ".conv_branch2b2"]], dim=1)
@@ -341,14 +348,17 @@ class Engine:
                 s1, sh1 = P["bn"][name + ".bn_branch2b1"]
                 v = E(Mo, mid)
                 conv(t, name + ".conv_branch2a", None, v, cin, mid, 3, stride, fd, dims, odims, scale=s1, shift=sh1)
-                if same:
-                    rpost = xraw
-                else:
-                    rpost = E(Mo, cout)
-                    conv(t, name + ".conv_branch1", rpost, None, cin, cout, 1, stride, 1, dims, odims)
                 xn = E(Mo, cout) if nxt_same else None
                 tn = E(Mo, cout)
-                conv(v, name + ".conv_branch2b1", xn, tn, mid, cout, 3, 1, d, odims, odims, r_post=rpost, scale=nsc, shift=nsh, drop=ndrop)
+                if (name + ".skip_fused") in P["w"]:            # last conv + 1x1 skip conv as one two-source launch
+                    conv(v, name + ".skip_fused", xn, tn, mid, cout, 3, 1, d, odims, odims, in2=t, IC2=cin, scale=nsc, shift=nsh, drop=ndrop)
+                else:
+                    if same:
+                        rpost = xraw
+                    else:
+                        rpost = E(Mo, cout)
+                        conv(t, name + ".conv_branch1", rpost, None, cin, cout, 1, stride, 1, dims, odims)
+                    conv(v, name + ".conv_branch2b1", xn, tn, mid, cout, 3, 1, d, odims, odims, r_post=rpost, scale=nsc, shift=nsh, drop=ndrop)
                 if save:
                     S[name] = dict(t=t, v=v)
             else:
@@ -583,6 +593,10 @@ class Engine:
                 Din = E(Mi, cin)
                 if same:
                     dgrad(du, name + ".conv_branch2a", Din, cin, mid, 3, stride, fd, din, dout, epi=1, scale=sa, mask=sv["t"], r_post=D)
+                elif (name + ".skip_fused") in P["wt"]:        # both data gradients into t: 9 taps of du + one K segment of D
+                    seg2 = (dout[1][0], dout[1][1], din[1][0], din[1][1]) if V == 2 else None
+                    L.conv_igemm(du, P["wt"][name + ".skip_fused"], Din, None, N=N, IH=dout[0][0], IW=dout[0][1], IC=mid, OH=din[0][0], OW=din[0][1],
+                                 OC=cin, KH=3, KW=3, stride=1, dil=fd, pad=fd, mode=1, in2=D, IC2=cout, epi=1, scale=sa, mask=sv["t"], seg2=seg2)
                 else:
                     tmp = E(Mi, cin)
                     dgrad(D, name + ".conv_branch1", tmp, cin, cout, 1, stride, 1, din, dout)
