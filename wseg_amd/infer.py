@@ -1,6 +1,6 @@
 """Multi-scale CAM inference of contrast_infer.py:58-99 on the HIP kernels.
 
-8 forwards (4 scales x {orig, h-flip}); output #2 of the Net (the PCM-refined CAM); bilinear resize to
+8 inputs (4 scales x {orig, h-flip}; each pair is one batch-of-two forward); output #2 of the Net (the PCM-refined CAM); bilinear resize to
 the original size (align_corners=False), label gating, un-flip and the sum are ONE accumulate kernel per
 forward; clamp / per-class min-max normalise / argmax against the bg score are fused in `infer_finish`.
 """
@@ -17,15 +17,23 @@ def infer_image(model, img_list, label20, orig_size, alpha=0.26):
     H, W = orig_size
     lab = label20.to(dev).float().contiguous()
     sum_cam = torch.zeros(20, H, W, device=dev, dtype=torch.float32)
-    for i, img in enumerate(img_list):
+    imgs = []
+    for img in img_list:
         img = torch.as_tensor(img).to(dev).float()
-        if img.dim() == 3:
-            img = img.unsqueeze(0)
-        _, cam_rv, _, _ = model(img.contiguous())
+        imgs.append(img.unsqueeze(0) if img.dim() == 3 else img)
+    i = 0
+    while i < len(imgs):
+        # an image and its flipped copy (same size, consecutive in the MSF order) go through the net as ONE batch of two: every
+        # op of the eval forward is per image, so the maps are those of two separate forwards (contrast_infer.py:58-66 runs 8)
+        pair = i + 1 < len(imgs) and imgs[i + 1].shape == imgs[i].shape and imgs[i].shape[0] == 1
+        batch = torch.cat(imgs[i:i + 2]) if pair else imgs[i]
+        _, cam_rv, _, _ = model(batch.contiguous())
         hs, ws = cam_rv.shape[2], cam_rv.shape[3]
-        # planes 1..20 of image 0 (contrast_infer.py:62 `cam[:, 1:, :, :]`, `[0]`)
-        L.resize_planar_fwd(cam_rv[0, 1:].contiguous(), sum_cam, 20, hs, ws, H, W, False, plane_mul=lab,
-                            flip_x=(i % 2 == 1), accumulate=True)
+        for j in range(2 if pair else 1):
+            # planes 1..20 of the image (contrast_infer.py:62 `cam[:, 1:, :, :]`, `[0]`)
+            L.resize_planar_fwd(cam_rv[j, 1:].contiguous(), sum_cam, 20, hs, ws, H, W, False, plane_mul=lab,
+                                flip_x=((i + j) % 2 == 1), accumulate=True)
+        i += 2 if pair else 1
     stats = torch.empty(20, 6, device=dev, dtype=torch.float32)
     L.plane_stats(sum_cam, stats, 20, H * W)
     norm_cam = torch.empty(20, H, W, device=dev, dtype=torch.float32)
