@@ -30,5 +30,5 @@ for _ in range(n_img):
     norm_cam, pred, cam_dict = infer_image(model, lst, label, (H, W))
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
-print(f"inference {prec}: {n_img / dt:.2f} images/s ({dt / n_img * 1e3:.1f} ms per image, 8 inputs = 4 batch-of-two forwards, {H}x{W}); "
+print(f"inference {prec}: {n_img / dt:.2f} images/s ({dt / n_img * 1e3:.1f} ms per image, 8 inputs = 2 two-segment launch sequences of batch-of-two, {H}x{W}); "
       f"1449 val images would take {1449 * dt / n_img:.0f} s")

@@ -21,19 +21,36 @@ def infer_image(model, img_list, label20, orig_size, alpha=0.26):
     for img in img_list:
         img = torch.as_tensor(img).to(dev).float()
         imgs.append(img.unsqueeze(0) if img.dim() == 3 else img)
-    i = 0
+    # an image and its flipped copy (same size, consecutive in the MSF order) go through the net as ONE batch of two: every op
+    # of the eval forward is per image, so the maps are those of two separate forwards (contrast_infer.py:58-66 runs 8)
+    batches, i = [], 0
     while i < len(imgs):
-        # an image and its flipped copy (same size, consecutive in the MSF order) go through the net as ONE batch of two: every
-        # op of the eval forward is per image, so the maps are those of two separate forwards (contrast_infer.py:58-66 runs 8)
         pair = i + 1 < len(imgs) and imgs[i + 1].shape == imgs[i].shape and imgs[i].shape[0] == 1
-        batch = torch.cat(imgs[i:i + 2]) if pair else imgs[i]
-        _, cam_rv, _, _ = model(batch.contiguous())
-        hs, ws = cam_rv.shape[2], cam_rv.shape[3]
-        for j in range(2 if pair else 1):
-            # planes 1..20 of the image (contrast_infer.py:62 `cam[:, 1:, :, :]`, `[0]`)
-            L.resize_planar_fwd(cam_rv[j, 1:].contiguous(), sum_cam, 20, hs, ws, H, W, False, plane_mul=lab,
-                                flip_x=((i + j) % 2 == 1), accumulate=True)
+        batches.append((i, torch.cat(imgs[i:i + 2]).contiguous() if pair else imgs[i].contiguous()))
         i += 2 if pair else 1
+    # ... and two such batches of DIFFERENT sizes are the two row segments of one launch sequence (the engine's two-view form,
+    # as the training step batches its 448x448 and 128x128 views): largest with smallest, so both sequences fill the chip
+    eng = getattr(model, "_engine", None)
+    order = sorted(range(len(batches)), key=lambda k: batches[k][1].shape[2] * batches[k][1].shape[3])
+    jobs, maps = [], {}
+    while order:
+        a = order.pop()
+        b = next((k for k in order if batches[k][1].shape[0] == batches[a][1].shape[0]), None) if eng is not None else None
+        if b is not None:
+            order.remove(b)
+        jobs.append((a, b))
+    for a, b in jobs:
+        if b is None:
+            outs = [model(batches[a][1])]
+        else:
+            eng.ensure_flat(dev)
+            outs, _ = eng.run_forward([batches[a][1].float(), batches[b][1].float()], save=False)
+        for k, out in zip((a, b), outs):
+            for j in range(out[1].shape[0]):
+                maps[batches[k][0] + j] = out[1][j, 1:].contiguous()      # planes 1..20 (contrast_infer.py:62 `cam[:, 1:, :, :]`, `[0]`)
+    for idx in sorted(maps):                                 # accumulate in the reference's order (same float sums)
+        m = maps[idx]
+        L.resize_planar_fwd(m, sum_cam, 20, m.shape[1], m.shape[2], H, W, False, plane_mul=lab, flip_x=(idx % 2 == 1), accumulate=True)
     stats = torch.empty(20, 6, device=dev, dtype=torch.float32)
     L.plane_stats(sum_cam, stats, 20, H * W)
     norm_cam = torch.empty(20, H, W, device=dev, dtype=torch.float32)
