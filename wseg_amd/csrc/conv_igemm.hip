@@ -1152,8 +1152,15 @@ extern "C" int wseg_conv_igemm(const wseg_conv_desc* d, void* stream) {
     const long rounds = (t256 + 255) / 256;
     static const int auto256 = getenv("WSEG_CONV256") ? atoi(getenv("WSEG_CONV256")) : 1;   // (0: A/B switch)
     static const int split_tail = getenv("WSEG_CONV_SPLIT") ? atoi(getenv("WSEG_CONV_SPLIT")) : 0;
+    // Tile choice by CU time in units of (32 rows x 256 columns x K) at the 256-tile kernel's rate: a round of NI-block tiles
+    // costs NI, a round of the 128^2 kernel (two resident workgroups of 2 units each, 0.75 of that rate) 5.33.  Fitted on the
+    // training AND the inference geometries (scripts/bench_conv_infer.py: 25 000-row launches ran 15-40 % faster on 224-row
+    // tiles than on the 128^2 kernel the previous rule — at least 200 tiles, last round 80 % full — gave them).
+    const long t224 = ((M + 223) / 224) * ((d->OC + 255) / 256), t128 = ((M + 127) / 128) * ((d->OC + 127) / 128);
+    const double c_big = std::min((double)rounds * 8.0, (double)((t224 + 255) / 256) * 7.0), c_128 = (double)((t128 + 511) / 512) * 5.33;
+    const bool by_cost = auto256 == 2 ? (t256 >= 200 && (double)t256 / (double)(rounds * 256) >= 0.80) : c_big <= c_128;
     big = d->bm_hint == 256 || d->bm_hint == 257 || d->bm_hint == 224 || d->in2 != nullptr ||
-          (auto256 && ((t256 >= 200 && (double)t256 / (double)(rounds * 256) >= 0.80) || (split_tail && d->bm_hint == 0 && t256 >= 256)));
+          (auto256 && (by_cost || (split_tail && d->bm_hint == 0 && t256 >= 256)));
     if (big)
       WSEG_CHECK(d->IH <= 16384 && d->IW <= 16384 && d->OH <= 16384 && d->OW <= 16384 && d->pad <= 4096 &&
                  (long)d->N * d->IH * d->IW + (long)d->N * d->IH2 * d->IW2 < (1L << 31), "conv_igemm: shape too large for the 256-tile kernel");
