@@ -27,6 +27,10 @@ extern "C" {
 #define WSEG_BF16 1
 
 int wseg_version(void);
+/* sizeof(wseg_conv_desc) / sizeof(wseg_wgrad_desc) as this build sees them: a binding checks its mirror of the descriptors against
+ * these before the first call (a stale, shorter mirror would hand the kernels uninitialised trailing fields). */
+size_t wseg_sizeof_conv_desc(void);
+size_t wseg_sizeof_wgrad_desc(void);
 const char* wseg_last_error(void);
 
 /* ---- convolution as implicit GEMM ------------------------------------------------------

@@ -65,6 +65,11 @@ def _load():
     lib = C.CDLL(LIB_PATH)
     lib.wseg_last_error.restype = C.c_char_p
     lib.wseg_version.restype = C.c_int
+    lib.wseg_sizeof_conv_desc.restype = C.c_size_t
+    lib.wseg_sizeof_wgrad_desc.restype = C.c_size_t
+    if lib.wseg_sizeof_conv_desc() != C.sizeof(ConvDesc) or lib.wseg_sizeof_wgrad_desc() != C.sizeof(WgradDesc):
+        raise ImportError(f"{LIB_PATH} was built from another include/wseg_hip.h (descriptor sizes "
+                          f"{lib.wseg_sizeof_conv_desc()}/{lib.wseg_sizeof_wgrad_desc()} vs {C.sizeof(ConvDesc)}/{C.sizeof(WgradDesc)}): rebuild it")
     return lib
 
 

@@ -12,7 +12,9 @@ void wseg_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* wseg_last_error(void) { return g_err; }
-extern "C" int wseg_version(void) { return 100; }
+extern "C" int wseg_version(void) { return 101; }
+extern "C" size_t wseg_sizeof_conv_desc(void) { return sizeof(wseg_conv_desc); }
+extern "C" size_t wseg_sizeof_wgrad_desc(void) { return sizeof(wseg_wgrad_desc); }
 
 namespace {
 
