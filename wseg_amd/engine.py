@@ -139,9 +139,11 @@ class Engine:
         shift = (bn.bias.detach().float() - bn.running_mean.float() * scale).to(device)
         return scale.contiguous(), shift.contiguous()
 
-    def ensure_packs(self, device, dt):
+    def ensure_packs(self, device, dt, defer_wt=False):
         """Packed (cast / transposed) weights + folded BatchNorms.  Frozen pieces (every BN, conv1a, b2*) are
-        cached on their own key so a training step only re-packs the 40 trainable tensors."""
+        cached on their own key so a training step only re-packs the 40 trainable tensors.
+        defer_wt: the transposed (dgrad) packs are only needed by the backward pass — the fused training step lets
+        `finish_packs()` make them on a side stream during the loss phase, when the chip is mostly idle."""
         net = self.net
         tdt = L.TORCH_DTYPE[dt]
         frozen_names = [c[0] for b in arch.BLOCKS if b[0] in arch.FROZEN_BLOCKS for c in arch.block_convs(b)]
@@ -202,10 +204,7 @@ class Engine:
                 t64 += ((co + 63) // 64) * ((ci + 63) // 64) * T_
             self._wt_table64 = torch.tensor(rows64, dtype=torch.int64, device=device)
             self._wt_tiles64 = t64
-        if dt == L.BF16:                                     # from the bf16 mirror (written by the fused SGD): a third of the traffic
-            L.pack_transposed_batch_bf16(mirror, self.flat_wt, self._wt_table64, self._wt_table64.shape[0], self._wt_tiles64)
-        else:
-            L.pack_transposed_batch(self.flat_w, self.flat_wt, self._wt_table, self._wt_table.shape[0], self._wt_tiles, dt)
+        self._wt_pending = (dt, mirror)
         for b in arch.BLOCKS:
             if b[0] in arch.FROZEN_BLOCKS:
                 continue
@@ -223,13 +222,9 @@ class Engine:
                     nm, cin_, mid_, cout_ = b[0], b[2], b[3], b[4]
                     P["w"][nm + ".skip_fused"] = torch.cat([P["w"][nm + ".conv_branch2b1"].reshape(cout_, 9 * mid_),
                                                              P["w"][nm + ".conv_branch1"].reshape(cout_, cin_)], dim=1)
-                    P["wt"][nm + ".skip_fused"] = torch.cat([P["wt"][nm + ".conv_branch2a"].reshape(cin_, 9 * mid_),
-                                                              P["wt"][nm + ".conv_branch1"].reshape(cin_, cout_)], dim=1)
             for b in arch.BLOCKS:
                 if b[1] != "res" and b[0] not in arch.FROZEN_BLOCKS and b[2] == b[4] // 2 and b[5] == 1 and b[4] % 256 == 0:
                     P["w"][b[0] + ".skip_fused"] = torch.cat([P["w"][b[0] + ".conv_branch1"], P["w"][b[0] + ".conv_branch2b2"]], dim=1)
-                    # backward twin: d_t = D . W_branch1 + du1 . W_branch2a  (transposed packs [cin][1][cout] | [cin][1][cout/4])
-                    P["wt"][b[0] + ".skip_fused"] = torch.cat([P["wt"][b[0] + ".conv_branch1"], P["wt"][b[0] + ".conv_branch2a"]], dim=2)
         # fused head: rows [fc_proj | fc8 | 0]; its transposed pack is made from the two f32 masters directly
         wh = torch.zeros(HEAD_LD, 1, 4096, device=device, dtype=tdt)
         wht = torch.zeros(4096, 1, HEAD_LD, device=device, dtype=tdt)
@@ -249,7 +244,33 @@ class Engine:
         L.pack_weights(w9p, wf, wt, 192, 1, 195, 192, FEAT_LD, dt)
         P["w"]["f9"], P["wt"]["f9"] = wf, wt
         self.packs, self.pack_key = P, key
+        if not defer_wt:
+            self.finish_packs()
         return P
+
+    def finish_packs(self):
+        """The transposed (dgrad) packs [IC][T][OC] of the current weights: ONE launch over all layers into the flat buffer the
+        `P["wt"]` views point into, plus the K-concatenated backward packs of the two-source launches.  Runs on the CURRENT
+        stream (the fused step calls it on a side stream and joins before the backward pass); no-op when already done."""
+        pend = getattr(self, "_wt_pending", None)
+        if pend is None:
+            return
+        self._wt_pending = None
+        dt, mirror = pend
+        P = self.packs
+        if dt == L.BF16:                                     # from the bf16 mirror (written by the fused SGD): a third of the traffic
+            L.pack_transposed_batch_bf16(mirror, self.flat_wt, self._wt_table64, self._wt_table64.shape[0], self._wt_tiles64)
+        else:
+            L.pack_transposed_batch(self.flat_w, self.flat_wt, self._wt_table, self._wt_table.shape[0], self._wt_tiles, dt)
+        for b in arch.BLOCKS:
+            nm, cin_, mid_, cout_ = b[0], b[2], b[3], b[4]
+            if (nm + ".skip_fused") not in P["w"]:
+                continue
+            if b[1] == "res":     # d_t = dgrad_3x3(du; W_2a) + D . W_branch1: nine taps of du, then one K segment of D
+                wt = torch.cat([P["wt"][nm + ".conv_branch2a"].reshape(cin_, 9 * mid_), P["wt"][nm + ".conv_branch1"].reshape(cin_, cout_)], dim=1)
+            else:                 # d_t = D . W_branch1 + du1 . W_branch2a  (transposed packs [cin][1][cout] | [cin][1][cout/4])
+                wt = torch.cat([P["wt"][nm + ".conv_branch1"], P["wt"][nm + ".conv_branch2a"]], dim=2)
+            P["wt"][nm + ".skip_fused"] = wt
 
     # ------------------------------------------------------------------ dropout
     MASK_SPECS = (("b6.dropout_2b1", 512, 0.3), ("b6.dropout_2b2", 1024, 0.3),
@@ -448,6 +469,7 @@ class Engine:
         """grads: per view (g_cam, g_cam_rv, g_fproj, g_rvd) — gradients of the view's four outputs (any may be
         None); in the fused (lowres) path g_cam / g_cam_rv are gradients of the stride-8 maps and `d_head_rows`
         (joint rows [f_proj | cam | pad]) may be supplied directly.  Accumulates into flat_g."""
+        self.finish_packs()                                  # (no-op when the caller already made the transposed packs)
         P = self.packs
         dt = S["dt"]
         tdt = L.TORCH_DTYPE[dt]

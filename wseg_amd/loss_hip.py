@@ -29,6 +29,13 @@ def _side_streams(eng, dev):
     return st
 
 
+def _aux_stream(eng, dev):
+    st = getattr(eng, "_aux_stream", None)
+    if st is None or st.device != dev:
+        st = eng._aux_stream = torch.cuda.Stream(dev)
+    return st
+
+
 def cpu_tie_pattern(P, k, device=None):
     """Q5: the index set torch.topk returns for a fully tied row of length P on the CPU library the
     reference's CPU path uses.  Data independent; computed once per (P, k) (and uploaded once per device)."""
@@ -161,9 +168,10 @@ def _rand_flags(y_dev, rng, P):
     return flags.to(y_dev.device)
 
 
-def step(model, img1, img2, label20, bg_threshold=0.20, rng=None, rng_parity=False, bg_topk_idx=None):
-    """Forward both views, all losses, backward into the engine's flat gradient buffer.
-    Returns the 8 logged scalars (device tensors)."""
+def step(model, img1, img2, label20, bg_threshold=0.20, rng=None, rng_parity=False, bg_topk_idx=None, zero_grads=False):
+    """Forward both views, all losses, backward into the engine's flat gradient buffer (accumulating; zero_grads=True clears
+    the buffer first — on a side stream during the loss phase, where it costs nothing).  Returns the 8 logged scalars
+    (device tensors)."""
     eng = model._engine
     dev = img1.device
     N = img1.shape[0]
@@ -172,7 +180,10 @@ def step(model, img1, img2, label20, bg_threshold=0.20, rng=None, rng_parity=Fal
     label20 = label20.to(dev).float().contiguous()
     eng.ensure_flat(dev)
     eng.attach_grads()
-    eng.ensure_packs(dev, L.BF16 if model.precision == "bf16" else L.F32)
+    defer = os.environ.get("WSEG_DEFER_PACKS", "1") != "0"      # (0: A/B switch — packs and memset before the forward pass)
+    eng.ensure_packs(dev, L.BF16 if model.precision == "bf16" else L.F32, defer_wt=defer)
+    if zero_grads and not defer:
+        eng.flat_g.zero_()
     acc = torch.zeros(8, device=dev, dtype=torch.float32)   # [cls1+cls2, (rvmin1+rvmin2)/2, er_sum, ecr, cross, cross2, intra]
     # The two views are independent until ER/ECR: run each on its own HIP stream so the small 128x128 view's
     # launches (which cannot fill 256 CUs) overlap with the 448x448 view's.
@@ -183,6 +194,14 @@ def step(model, img1, img2, label20, bg_threshold=0.20, rng=None, rng_parity=Fal
     # losses then run on their own HIP streams.
     outs, ctx = eng.run_forward([img1, img2], save=True, lowres=True)
     fork = main.record_event()
+    # Backward-only preparation — the transposed weight packs (420 MB of traffic) and the gradient memset (420 MB) — on a third
+    # stream behind the forward pass: it runs while the loss phase's small kernels leave the chip's bandwidth idle.
+    aux = _aux_stream(eng, dev) if use_streams else main
+    aux.wait_event(fork)
+    with torch.cuda.stream(aux):
+        eng.finish_packs()
+        if zero_grads and defer:
+            eng.flat_g.zero_()
     P = N * 256
     tie_idx = (bg_topk_idx.to(device=dev, dtype=torch.int32) if bg_topk_idx is not None else cpu_tie_pattern(P, 32, dev))
     views = []
@@ -273,6 +292,7 @@ def step(model, img1, img2, label20, bg_threshold=0.20, rng=None, rng_parity=Fal
     d_head = torch.empty_like(ctx["head"])
     for v in views:
         L.head_grad_fused(v.dF, v.d_cam_low, v.head, d_head[v.off:], HEAD_LD, N, v.h, v.w, 16, 16)
+    main.wait_stream(aux)
     eng.run_backward(ctx, [(None, v.d_rvd, None, None) for v in views], d_head_rows=d_head)
     loss_cls = acc[0] * 0.5 + acc[1]
     loss_er = acc[2] * er_coef

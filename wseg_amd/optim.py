@@ -88,15 +88,17 @@ class PolyOptimizer(torch.optim.SGD):
                 eng.flat_wb_version = eng.flat_w_version
         self.global_step += 1
 
-    def zero_grad(self, set_to_none=True):
-        """Flat-backed gradients are zeroed in place (one memset) instead of being dropped."""
+    def zero_grad(self, set_to_none=True, flat=True):
+        """Flat-backed gradients are zeroed in place (one memset) instead of being dropped; flat=False leaves that memset to
+        the caller (wseg_amd.train: the fused step does it on a side stream)."""
         done = set()
         for g in self.param_groups:
             for p in g['params']:
                 info = getattr(p, "_wseg_flat", None)
                 if info is not None and p.grad is not None and p.grad.data_ptr() == info[0].flat_g.data_ptr() + 4 * info[1]:
                     if id(info[0]) not in done:
-                        info[0].flat_g.zero_()
+                        if flat:
+                            info[0].flat_g.zero_()
                         done.add(id(info[0]))
                 elif p.grad is not None:
                     if set_to_none:

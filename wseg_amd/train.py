@@ -67,7 +67,8 @@ class Trainer:
         model, opt = self.model, self.optimizer
         img1 = img1.contiguous().float()
         img2 = second_view(img1)
-        opt.zero_grad()
+        fused = self.loss_impl != "aten"
+        opt.zero_grad(flat=not fused)                       # (the fused step clears the flat gradient buffer itself, off the critical path)
         if self.loss_impl == "aten":
             out1 = model(img1)
             out2 = model(img2)
@@ -77,7 +78,7 @@ class Trainer:
         else:
             from . import loss_hip
             losses = loss_hip.step(model, img1, img2, label20, self.bg_threshold, self.rng, self.rng_parity,
-                                   self.bg_topk_idx)
+                                   self.bg_topk_idx, zero_grads=True)
         if self.distributed:
             if self._pending:                               # bucketed all-reduces launched during backward
                 for work in self._pending:
