@@ -120,6 +120,10 @@ int wseg_dropout_scale(const float* u, float* out, long total, long split_at, fl
 int wseg_stem_conv(const float* x_nchw, const float* w /*[64][3][3][3] = [oc][ky][kx][ic]*/,
                    const float* scale, const float* shift, void* raw, void* act,
                    int N, int H, int W, int dtype, void* stream);
+/* the same with the weights transposed to [27 = (ky*3+kx)*3+ic][64 oc] (f32): the channel pairs become packed FMAs — same products,
+ * same order, same results, half the vector instructions (conv1a is frozen: the caller transposes once). */
+int wseg_stem_conv_kc(const float* x, const float* w_kc, const float* scale, const float* shift,
+                      void* raw, void* act, int N, int H, int W, int dtype, void* stream);
 
 /* ---- CAM head (network/resnet38_contrast.py:34-59) -------------------------------------------
  * Fused head GEMM rows are [f_proj(128) | cam logits(21) | zero pad] (ld = 192).

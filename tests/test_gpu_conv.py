@@ -141,6 +141,11 @@ def test_stem(dt):
     tol = dict(rtol=1e-5, atol=1e-5) if dt == "f32" else dict(rtol=1e-2, atol=2e-2)
     np.testing.assert_allclose(raw_g.float().cpu().numpy(), _nhwc(y).numpy(), **tol)
     np.testing.assert_allclose(act_g.float().cpu().numpy(), _nhwc(act).numpy(), **tol)
+    # packed-FMA form on the transposed weights [27][64]: the same products in the same order -> bit-identical
+    raw_k, act_k = torch.empty_like(raw_g), torch.empty_like(act_g)
+    L.stem_conv_kc(x.to(dev), w.permute(2, 3, 1, 0).reshape(27, 64).contiguous().to(dev), scale.to(dev), shift.to(dev), raw_k, act_k, N, H, W,
+                   L.dtype_code(raw_g))
+    assert torch.equal(raw_k, raw_g) and torch.equal(act_k, act_g)
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])

@@ -174,6 +174,14 @@ def dropout_scale(u, out, split_at, p0, p1):
                                  C.c_float(p0), C.c_float(p1), C.c_void_p(stream_ptr())), "wseg_dropout_scale")
 
 
+def stem_conv_kc(x, w_kc, scale, shift, raw, act, N, H, W, dtype):
+    if w_kc.numel() != 27 * 64 or w_kc.dtype != torch.float32:
+        raise RuntimeError("stem_conv_kc: weights must be f32 [27][64]")
+    check(lib.wseg_stem_conv_kc(C.c_void_p(_ptr(x)), C.c_void_p(_ptr(w_kc)), C.c_void_p(_ptr(scale)), C.c_void_p(_ptr(shift)),
+                                C.c_void_p(_ptr(raw)), C.c_void_p(_ptr(act)), N, H, W, dtype,
+                                C.c_void_p(stream_ptr())), "wseg_stem_conv_kc")
+
+
 def stem_conv(x, w, scale, shift, raw, act, N, H, W, dtype):
     check(lib.wseg_stem_conv(C.c_void_p(_ptr(x)), C.c_void_p(_ptr(w)), C.c_void_p(_ptr(scale)), C.c_void_p(_ptr(shift)),
                              C.c_void_p(_ptr(raw)), C.c_void_p(_ptr(act)), N, H, W, dtype,

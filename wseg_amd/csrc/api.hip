@@ -109,7 +109,9 @@ __global__ void dropout_scale_kernel(const float* __restrict__ u, float* __restr
 }
 
 // ---- stem: conv1a 3->64 3x3 pad 1 from NCHW f32, fused BN-ReLU, NHWC out -------------------
-template <int DT>
+// KC = 1: weights transposed to [k = (ky*3+kx)*3+ic][64 oc]: two adjacent channels are then one SGPR pair and the FMA loop is
+// 216 v_pk_fma_f32 (input broadcast by op_sel) instead of 432 v_fma_f32 — same products, same order, same IEEE fused results.
+template <int DT, int KC = 0>
 __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                    const float* __restrict__ scale, const float* __restrict__ shift,
                                                    void* raw, void* act, int N, int H, int W) {
@@ -138,6 +140,23 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
       }
     }
   float acc[16];
+  if constexpr (KC == 1) {
+    typedef float f2_t __attribute__((ext_vector_type(2)));
+    const f2_t* wg2 = reinterpret_cast<const f2_t*>(w + cg * 16);   // [k][64 oc]: row stride 32 pairs, wave-uniform base
+    f2_t a2[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) a2[o] = (f2_t){0.f, 0.f};
+#pragma unroll
+    for (int ic = 0; ic < 3; ++ic)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const f2_t xv = {in[t * 3 + ic], in[t * 3 + ic]};
+#pragma unroll
+        for (int o = 0; o < 8; ++o) a2[o] = __builtin_elementwise_fma(xv, wg2[(t * 3 + ic) * 32 + o], a2[o]);
+      }
+#pragma unroll
+    for (int o = 0; o < 8; ++o) { acc[2 * o] = a2[o].x; acc[2 * o + 1] = a2[o].y; }
+  } else {
   const float* wg = w + (size_t)cg * 16 * 27;                       // [oc][ky][kx][ic], wave-uniform base
 #pragma unroll
   for (int o = 0; o < 16; ++o) {
@@ -148,6 +167,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
 #pragma unroll
       for (int t = 0; t < 9; ++t) a = fmaf(in[t * 3 + ic], wg[o * 27 + t * 3 + ic], a);
     acc[o] = a;
+  }
   }
   const size_t pix0 = ((size_t)n * H + y) * W + bx * 64;
   const int npx = min(64, W - bx * 64);
@@ -193,6 +213,19 @@ extern "C" int wseg_pack_weights(const float* master, void* fwd, void* tr, int O
     if (dtype == WSEG_BF16) hipLaunchKernelGGL(pack_tr_kernel<WSEG_BF16>, grid, dim3(32, 8), 0, s, master, tr, OC, T, IC, OCp, ICp);
     else hipLaunchKernelGGL(pack_tr_kernel<WSEG_F32>, grid, dim3(32, 8), 0, s, master, tr, OC, T, IC, OCp, ICp);
   }
+  WSEG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wseg_stem_conv_kc(const float* x, const float* w_kc, const float* scale, const float* shift,
+                                 void* raw, void* act, int N, int H, int W, int dtype, void* stream) {
+  WSEG_CHECK(x && w_kc && (raw || act), "stem_conv_kc: null pointer");
+  WSEG_CHECK(!act || (scale && shift), "stem_conv_kc: act needs scale/shift");
+  const long blocks = (long)N * H * ((W + 63) / 64);
+  WSEG_CHECK(blocks > 0 && blocks < (1L << 31), "stem_conv_kc: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == WSEG_BF16) hipLaunchKernelGGL((stem_kernel<WSEG_BF16, 1>), dim3((unsigned)blocks), dim3(256), 0, s, x, w_kc, scale, shift, raw, act, N, H, W);
+  else hipLaunchKernelGGL((stem_kernel<WSEG_F32, 1>), dim3((unsigned)blocks), dim3(256), 0, s, x, w_kc, scale, shift, raw, act, N, H, W);
   WSEG_LAUNCH_CHECK();
   return 0;
 }

@@ -149,7 +149,7 @@ class Engine:
         frozen_names = [c[0] for b in arch.BLOCKS if b[0] in arch.FROZEN_BLOCKS for c in arch.block_convs(b)]
         fkey = (dt, str(device)) + tuple(b._version for b in net.buffers()) + \
             tuple(p._version for n_, p in net.named_parameters() if ".bn" in n_ or n_.startswith("bn7")) + \
-            tuple(self.conv_param(n_)._version for n_ in frozen_names)
+            tuple(self.conv_param(n_)._version for n_ in frozen_names) + (net.conv1a.weight._version, net.conv1a.weight.data_ptr())
         if getattr(self, "_frozen_packs", None) is None or self._frozen_key != fkey:
             F_ = {"w": {}, "bn": {}}
             for b in arch.BLOCKS:
@@ -161,6 +161,7 @@ class Engine:
                         L.pack_weights(self.conv_param(cname).detach(), wf, None, co, k * k, ci, co, ci, dt)
                         F_["w"][cname] = wf
             F_["bn"]["bn7"] = self._bn_fold("bn7", device)
+            F_["w"]["conv1a_kc"] = net.conv1a.weight.detach().to(device).float().permute(2, 3, 1, 0).reshape(27, 64).contiguous()   # [k = (ky*3+kx)*3+ic][oc] for the packed-FMA stem
             self._frozen_packs, self._frozen_key = F_, fkey
             self.packs = None
         names = self.trainable_order()
@@ -355,7 +356,7 @@ class Engine:
         sc, sh = P["bn"]["b2.bn_branch2a"]
         t = E(rows_of(dims), 64)
         for x, off, (H, W) in zip(xs, offs_of(dims), dims):
-            L.stem_conv(x, net.conv1a.weight.detach(), sc, sh, None, t[off:], N, H, W, dt)
+            L.stem_conv_kc(x, P["w"]["conv1a_kc"], sc, sh, None, t[off:], N, H, W, dt)
         xraw = None
         for i, b in enumerate(arch.BLOCKS):
             name, kind, cin, mid, cout, stride, fd, d, p = b
