@@ -273,3 +273,31 @@ def test_full_size_step_properties(proc_sd):
     opt._PolyOptimizer__initial_lr = [1e-3 for _ in opt.param_groups]
     tr.step(img, lab)
     assert float((eng.flat_w - w0).abs().max()) > 0
+
+
+def test_packs_follow_the_weights_bf16(proc_sd):
+    """After optimizer steps every derived weight buffer of the bf16 path — the cast mirror, the transposed dgrad packs (made on
+    a side stream during the loss phase) and the K-concatenated packs of the two-source launches — equals what the CURRENT master
+    weights give (a stale pack would train on last step's weights without any error)."""
+    from wseg_amd import _lib as L, synth
+    n, size, seed = 2, 96, 31
+    model, opt, tr = _trainer(proc_sd, "bf16", "hip", n, seed, 3, lr=0.05)
+    eng = model._engine
+    for _ in range(2):
+        tr.step(synth.synthetic_images(n, size, seed).cuda(), synth.synthetic_labels(n, seed).cuda())
+    P = eng.ensure_packs(torch.device("cuda", torch.cuda.current_device()), L.BF16)      # (+ the deferred transposed packs)
+    torch.cuda.synchronize()
+    changed = 0
+    for name in ("b7.conv_branch1", "b7.conv_branch2b2", "b7.conv_branch2a", "b6.conv_branch1", "b5.conv_branch2b1", "b5.conv_branch2a", "b4_2.conv_branch2a"):
+        w = eng.conv_param(name).detach()                                   # logical [OC, IC, KH, KW] view of the master
+        okkc = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1, w.shape[1]).to(torch.bfloat16)
+        assert torch.equal(P["w"][name], okkc), name
+        assert torch.equal(P["wt"][name], okkc.permute(2, 1, 0).contiguous()), name
+        changed += int(not torch.equal(okkc.float(), proc_sd[name + ".weight"].permute(0, 2, 3, 1).reshape(okkc.shape).cuda().to(torch.bfloat16).float()))
+    assert changed > 0                                                       # the steps did move the weights
+    for blk, a, b in (("b7", "conv_branch1", "conv_branch2b2"), ("b6", "conv_branch1", "conv_branch2b2")):
+        f = P["w"][blk + ".skip_fused"]
+        assert torch.equal(f.reshape(f.shape[0], -1), torch.cat([P["w"][f"{blk}.{a}"].reshape(f.shape[0], -1), P["w"][f"{blk}.{b}"].reshape(f.shape[0], -1)], dim=1))
+        ft = P["wt"][blk + ".skip_fused"]
+        assert torch.equal(ft.reshape(ft.shape[0], -1), torch.cat([P["wt"][f"{blk}.conv_branch1"].reshape(ft.shape[0], -1),
+                                                                     P["wt"][f"{blk}.conv_branch2a"].reshape(ft.shape[0], -1)], dim=1))
