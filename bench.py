@@ -1,7 +1,12 @@
 #!/usr/bin/env python
 """bench.py — training images/sec of the contrast_train hot path at B=16 x 448 x 448 per GPU.
 
-    python bench.py [--gpus N --steps K --warmup W]          (N>1: launched by torch.distributed.run)
+    python bench.py [--gpus N --steps K --warmup W]
+
+N>1: one process per GPU over RCCL.  Either the caller launches the ranks (`python -m torch.distributed.run --nproc-per-node N
+bench.py --gpus N ...`: RANK / WORLD_SIZE are in the environment) or — when RANK is unset — this process starts that launcher
+itself as a CHILD (before it has touched the GPU; it never re-execs) and exits with the child's return code.  A world size that
+differs from --gpus is an error, so a mislaunch cannot report a one-GPU number as an N-GPU one.
 
 One "step" = one full loop body of contrast_train.py:128-399 on a synthetic batch resident in HBM:
 second view, two ResNet-38d forwards, CAM/PCM head, all SEAM + contrast losses, backward,
@@ -10,6 +15,8 @@ gradient all-reduce (N>1), PolyOptimizer step.  Prints ONE JSON line (rank 0).
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,27 +34,75 @@ def conv_flops_model():
     return 2.4292e12
 
 
-def cpu_baseline(sample_n=2, size=448):
-    """The oracle (CPU restatement, pinned to the reference) timed on this box's host cores."""
+def cpu_baseline(sizes=(2, 16), size=448):
+    """The oracle (CPU restatement, pinned to the reference) timed on this box's host cores: BASELINE.md §3 — one warm-up step,
+    then one timed step (forward both views + loss + backward) at N=2 and at N=16."""
     import random
     from oracle import loss as oloss
     from oracle import net as onet
     from wseg_amd import synth
-    sd = synth.procedural_state_dict(0)
-    keys = onet.trainable_keys(sd)
-    for k in keys:
-        sd[k] = sd[k].clone().requires_grad_(True)
-    img = synth.synthetic_images(sample_n, size, 0)
-    lab = synth.synthetic_labels(sample_n, 0)
-    m1 = synth.synthetic_dropout_masks(sample_n, 0)
-    m2 = synth.synthetic_dropout_masks(sample_n, 1)
-    t0 = time.time()
-    out = oloss.train_step(img, lab, sd, m1, m2, 0.20, random.Random(0))
-    out["loss"].backward()
-    dt = time.time() - t0
-    return {"value": sample_n / dt, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 step (fwd both views + loss + bwd) of the CPU oracle at N={sample_n}, {size}x{size}, fp32, "
-                      f"{dt:.1f} s, nproc={os.cpu_count()}"}
+
+    def one(n):
+        sd = synth.procedural_state_dict(0)
+        for k in onet.trainable_keys(sd):
+            sd[k] = sd[k].clone().requires_grad_(True)
+        img = synth.synthetic_images(n, size, 0)
+        lab = synth.synthetic_labels(n, 0)
+        m1 = synth.synthetic_dropout_masks(n, 0)
+        m2 = synth.synthetic_dropout_masks(n, 1)
+        t0 = time.time()
+        out = oloss.train_step(img, lab, sd, m1, m2, 0.20, random.Random(0))
+        out["loss"].backward()
+        return time.time() - t0
+
+    one(1)                                                  # warm-up (thread pool, allocator, oneDNN primitive caches)
+    runs = [(n, one(n)) for n in sizes]
+    n, dt = runs[-1]
+    return {"value": round(n / dt, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "1 warm-up step (N=1) then 1 timed step (fwd both views + loss + bwd) of the CPU oracle, fp32, "
+                      f"{size}x{size}: " + "; ".join(f"N={n_}: {dt_:.1f} s = {n_ / dt_:.3f} img/s" for n_, dt_ in runs)
+                      + f"; value = the N={n} run; nproc={os.cpu_count()}"}
+
+
+def _spawn_ranks(a):
+    """--gpus N without a launcher: start `torch.distributed.run` as a child process (this process has made no GPU call)."""
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode          # rank 0's JSON line goes to the inherited stdout
+
+
+def timed_steps(trainer, img, lab, steps, warmup, barrier):
+    for _ in range(warmup):
+        trainer.step(img, lab)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        losses = trainer.step(img, lab)
+    barrier()
+    return time.perf_counter() - t0, losses
+
+
+def build_trainer(precision, lr, dev, rank):
+    import random
+    from wseg_amd import synth
+    from wseg_amd.optim import PolyOptimizer
+    from wseg_amd.resnet38_contrast import Net
+    from wseg_amd.train import Trainer
+    model = Net(precision=precision)
+    groups = _quiet(model.get_parameter_groups)
+    opt = PolyOptimizer([
+        {'params': groups[0], 'lr': lr, 'weight_decay': 5e-4},
+        {'params': groups[1], 'lr': 2 * lr, 'weight_decay': 0},
+        {'params': groups[2], 'lr': 10 * lr, 'weight_decay': 5e-4},
+        {'params': groups[3], 'lr': 20 * lr, 'weight_decay': 0}], lr=lr, weight_decay=5e-4, max_step=10582 // 16 * 8)
+    model.load_state_dict(synth.procedural_state_dict(0, device=dev))
+    model.cuda(dev)
+    model.train()
+    return model, Trainer(model, opt, 0.20, random.Random(1000 + rank), False)
 
 
 def main():
@@ -57,18 +112,27 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--size", type=int, default=448)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--loss", default=os.environ.get("WSEG_LOSS", "hip"), choices=["hip", "aten"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16x3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-n", default="2,16", help="batch sizes of the CPU-oracle leg (BASELINE.md §3: N=2 and N=16)")
+    ap.add_argument("--parity-steps", type=int, default=2,
+                    help="timed steps of the parity (f32-exact) mode reported as `parity_mode` beside the bf16 line (0: skip)")
+    ap.add_argument("--parity-precision", default=os.environ.get("WSEG_PARITY_PRECISION", "fp32"), choices=["fp32", "bf16x3"])
     ap.add_argument("--event-stride", type=int, default=5, help="bracket every k-th conv launch with HIP events (rotating)")
+    ap.add_argument("--seed", type=int, default=0, help="base seed: rank r draws its images / labels / dropout masks / keys from seed + r")
     ap.add_argument("--lr", type=float, default=1e-5,
                     help="base lr; the reference's 0.01 makes the RANDOM procedural weights diverge within 2 steps "
                          "(measured, scripts/debug_step.py), so the bench steps with a small lr — same kernels, same work")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "RANK" not in os.environ:              # no launcher above us: be the launcher (child process, no exec)
+        sys.exit(_spawn_ranks(a))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch `python bench.py --gpus N` (it starts the ranks) "
+                         f"or `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     # WSEG_DIST_BACKEND=gloo: protocol rehearsal with several ranks on ONE card (RCCL refuses two ranks per device)
@@ -77,6 +141,7 @@ def main():
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    torch.manual_seed(a.seed + rank)                          # Dropout2d masks and hard-pixel keys differ per rank (they see different images)
     import torch.distributed as dist
     force_dist = os.environ.get("WSEG_FORCE_DIST", "0") == "1"     # one-rank RCCL group: exercises the exchange code on one GPU
     if world > 1 or force_dist:
@@ -91,24 +156,10 @@ def main():
 
     from wseg_amd import _lib as L
     from wseg_amd import synth
-    from wseg_amd.optim import PolyOptimizer
-    from wseg_amd.resnet38_contrast import Net
-    from wseg_amd.train import Trainer
 
-    model = Net(precision=a.precision)
-    groups = _quiet(model.get_parameter_groups)
-    opt = PolyOptimizer([
-        {'params': groups[0], 'lr': a.lr, 'weight_decay': 5e-4},
-        {'params': groups[1], 'lr': 2 * a.lr, 'weight_decay': 0},
-        {'params': groups[2], 'lr': 10 * a.lr, 'weight_decay': 5e-4},
-        {'params': groups[3], 'lr': 20 * a.lr, 'weight_decay': 0}], lr=a.lr, weight_decay=5e-4, max_step=10582 // 16 * 8)
-    model.load_state_dict(synth.procedural_state_dict(0, device=dev))
-    model.cuda(dev)
-    model.train()
-    import random
-    trainer = Trainer(model, opt, 0.20, random.Random(rank), False, a.loss)
-    img = synth.synthetic_images(a.batch, a.size, seed=rank, device=dev)
-    lab = synth.synthetic_labels(a.batch, seed=rank, device=dev)
+    model, trainer = build_trainer(a.precision, a.lr, dev, a.seed + rank)
+    img = synth.synthetic_images(a.batch, a.size, seed=a.seed + rank, device=dev)
+    lab = synth.synthetic_labels(a.batch, seed=a.seed + rank, device=dev)
 
     def barrier():
         if world > 1:
@@ -136,6 +187,7 @@ def main():
         dt = float(t.item())
     ms = dt / a.steps * 1e3
     value = a.batch * world * a.steps / dt
+    PEAKS = {"bf16": PEAK_BF16_TFLOPS, "fp32": PEAK_F32_TFLOPS, "bf16x3": PEAK_BF16_TFLOPS / 3}
 
     if rank == 0:
         # dominant kernel: the implicit-GEMM conv (fwd + dgrad launches), timed with HIP events on the
@@ -147,7 +199,7 @@ def main():
         tot_ms = sum(e[0] / e[1] for e in per_idx.values()) * a.steps     # = one step's launches, averaged over their samples
         tot_fl = sum(e[2] for e in per_idx.values()) * a.steps
         n_launch = max(1, len(per_idx)) * a.steps
-        peak = PEAK_BF16_TFLOPS if a.precision == "bf16" else PEAK_F32_TFLOPS
+        peak = PEAKS[a.precision]
         achieved = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
         traffic, traffic_src = None, None
         try:                                                   # HBM bytes per launch from the committed PMC passes
@@ -165,13 +217,28 @@ def main():
         line = {"metric": "training images/sec at B=16x448x448 (contrast_train step)", "value": round(value, 2),
                 "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                 "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": a.precision if a.precision == "bf16" else "f32", "data": "synthetic",
+                "dtype": {"bf16": "bf16", "fp32": "f32", "bf16x3": "bf16x3 (hi/lo split, f32 accumulate)"}[a.precision], "data": "synthetic",
                 "config": {"workload": f"ResNet-38 contrast, synthetic VOC {a.size}x{a.size}, B={a.batch}/GPU, "
-                                       f"procedural weights, dropout on, loss={a.loss}",
-                           "global_batch": a.batch * world, "parallelism": f"dp{world}"},
+                                       f"procedural weights, dropout on, fused HIP loss",
+                           "global_batch": a.batch * world, "parallelism": f"dp{world}", "seed": a.seed},
                 "loss": float(losses["loss"]), "roofline": roof}
+    # ---- the parity mode's throughput (the mode the 1e-4 / argmax-exact evidence is for), same workload, rank 0 at N=1 only
+    if rank == 0 and world == 1 and a.parity_steps > 0 and a.precision == "bf16":
+        del trainer, model
+        torch.cuda.empty_cache()
+        pmodel, ptrainer = build_trainer(a.parity_precision, a.lr, dev, a.seed + rank)
+        pdt, plosses = timed_steps(ptrainer, img, lab, a.parity_steps, 1, barrier)
+        pms = pdt / a.parity_steps * 1e3
+        ppeak = PEAKS[a.parity_precision]
+        line["parity_mode"] = {"precision": a.parity_precision, "ms_per_step": round(pms, 2), "value": round(a.batch * a.parity_steps / pdt, 2),
+                               "unit": "images/sec", "steps": a.parity_steps, "warmup": 1, "peak_tflops": round(ppeak, 1),
+                               "whole_step_frac": round(conv_flops_model() * a.batch / (pms * 1e-3) / 1e12 / ppeak, 4),
+                               "loss": float(plosses["loss"])}
+        del ptrainer, pmodel
+        torch.cuda.empty_cache()
+    if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
+            line["cpu_baseline"] = cpu_baseline(tuple(int(x) for x in a.cpu_baseline_n.split(",")))
         print(json.dumps(line), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -66,7 +66,8 @@ typedef struct wseg_conv_desc {
   int32_t relu_lt;     /* epi 0: ReLU on `out` channels < relu_lt (fused head: f_proj | cam); 0 = none */
   int32_t bm_hint;     /* 0 = library chooses the tile (64 / 128 pixel rows x 128 channels, or the 256 x 256 phase-pipelined
                           bf16 kernel for large layers with OC % 256 == 0, or the 512 x 128 one for OC = 128 layers with many pixels);
-                          64 / 128 / 256 = force; 257 / 258 / 259 = test hooks (row split, 256 x 128 tile, 512 x 128 tile) */
+                          64 / 128 / 224 / 256 = force; 257 / 259 = test hooks (row split, 512 x 128 tile); 258 and negative values: development
+                          probes, refused unless the library was built with -DWSEG_PROBES */
   /* optional SECOND row segment (the 128x128 view batched behind the 448x448 view in one launch): rows
    * [0, N*OH*OW) use (IH,IW,OH,OW); rows beyond use (IH2,IW2,OH2,OW2), same N, their input pixels follow the
    * first segment's N*IH*IW rows; drop then has 2N rows.  OH2 == 0: single segment. */
@@ -226,7 +227,9 @@ int wseg_proto_candidates(const float* ncam, const float* F, const int* tie_idx,
 int wseg_proto_merge(const float* cand_val, const float* cand_feat, const int* cand_const, float* protos, int world, int K,
                      long rank_stride /* 0: contiguous [world][...] arrays; else elements between consecutive ranks' blocks (one gathered buffer) */, void* stream);
 int wseg_nce_sims(const float* F, const float* p_own, const float* p_oth, float* fn, float* nrm, float* S_own, float* S_oth, int P, void* stream);
-int wseg_intra_weights(const int* y, const float* S_own, const float* rkey, const unsigned char* rand_flag, float* w, int P, void* stream);
+/* S_own: ld_s == 21: the [P,21] similarity table (the own-class entry is S_own[p*21 + y[p]]); ld_s == 1: one own-class similarity per pixel
+ * (row 1 of the records below) */
+int wseg_intra_weights(const int* y, const float* S_own, int ld_s, const float* rkey, const unsigned char* rand_flag, float* w, int P, void* stream);
 /* the same sampling over the GLOBAL batch under data parallelism (the reference runs :302-334 on the gathered batch):
  * intra_pack writes this rank's records rec[3][P] = {label (int bits), own-class similarity, random key}; after an
  * all-gather rank r's block lies at rec + r*rank_stride and intra_weights_global returns this rank's weights, multiplied by `scale`
@@ -236,6 +239,28 @@ int wseg_intra_weights_global(const float* rec, float* w, int P, int ranks, int 
 int wseg_nce_loss_grad(const float* fn, const float* nrm, const float* S_own, const float* S_oth, const int* y_own, const int* y_oth,
                        const float* w_intra, const float* p_own, const float* p_oth, float* dF, float* sums, int P,
                        float coef_cross, float coef_intra, void* stream);
+
+/* ---- fused pixel-to-prototype contrast: the product path of contrast_train.py:245-334 (nce_sims / nce_loss_grad above are its
+ * unfused reference formulation).  Two launches per step serve BOTH views; the normalised features and the [P,21] similarity rows
+ * never reach HBM: every launch reads the raw features once (P*128*4 B) and writes only records (12 B / pixel) or dF (P*128*4 B).
+ *   nce_records : rec[3][P] = {label (int bits), similarity of the pixel to its OWN class's prototype of p_own, rkey (when given)} — what the
+ *                 hard-pixel sampling (intra_weights / the all-gather + intra_weights_global) needs; fields used: F, p_own, y_own, rkey, rec
+ *   nce_fused   : similarities (exact-f32 MFMA) -> cross-prototype, cross-pseudo-label and intra-view InfoNCE (tau = 0.1) -> dF, and
+ *                 sums[0..2] += {cross, cross2, intra} * coef; fields used: F, p_own, p_oth, y_own, y_oth, w_intra, dF
+ * Per view v the "other" set is the other view's prototypes / labels (views[0] <-> views[1]); P rows each, D = 128, C = 21. */
+typedef struct {
+  const float* F;        /* [P][128] un-normalised projected features (f_proj resized to 16x16, rows n,i,j) */
+  const float* p_own;    /* [21][128] this view's prototypes */
+  const float* p_oth;    /* [21][128] the other view's prototypes */
+  const int32_t* y_own;  /* [P] this view's pseudo-labels */
+  const int32_t* y_oth;  /* [P] the other view's pseudo-labels */
+  const float* w_intra;  /* [P] hard-pixel weights (intra_weights*) */
+  const float* rkey;     /* [P] random keys copied into the records (nullable) */
+  float* rec;            /* [3][P] out (nce_records) */
+  float* dF;             /* [P][128] out (nce_fused) */
+} wseg_nce_view;
+int wseg_nce_records(const wseg_nce_view* views, int nviews, int P, void* stream);
+int wseg_nce_fused(const wseg_nce_view* views, int nviews, int P, float coef_cross, float coef_intra, float* sums /* [3], accumulated */, void* stream);
 
 /* ---- fused SGD step (tool/torchutils.py:23-33 -> torch.optim.SGD.step) ------------------------
  * One pass over the flat buffers: d = g*grad_scale + wd*p; buf = first ? d : momentum*buf + d;

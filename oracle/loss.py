@@ -186,11 +186,12 @@ def step_loss(out1, out2, label20, bg_threshold=0.20, rng=None, extras=None):
                 loss_cross_nce=loss_cross_nce, loss_cross_nce2=loss_cross_nce2)
 
 
-def train_step(img1, label20, sd, masks1=None, masks2=None, bg_threshold=0.20, rng=None, extras=None):
-    """One loop body, contrast_train.py:130-395: second view, two forwards, the loss."""
+def train_step(img1, label20, sd, masks1=None, masks2=None, bg_threshold=0.20, rng=None, extras=None, gates1=None, gates2=None):
+    """One loop body, contrast_train.py:130-395: second view, two forwards, the loss.  gates1 / gates2: optional injected ReLU
+    decisions per view (oracle/net.py `_relu`)."""
     img2 = F.interpolate(img1, size=(128, 128), mode="bilinear", align_corners=True)
-    out1 = onet.net_forward(img1, sd, masks1)
-    out2 = onet.net_forward(img2, sd, masks2)
+    out1 = onet.net_forward(img1, sd, masks1, gates=gates1)
+    out2 = onet.net_forward(img2, sd, masks2, gates=gates2)
     if extras is not None:
         extras.update(out1=out1, out2=out2)
     return step_loss(out1, out2, label20, bg_threshold, rng, extras)

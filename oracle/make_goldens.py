@@ -190,17 +190,18 @@ def topk_pattern_golden(out_dir):
     print("wrote bg_topk_pattern", {k: v[:4].tolist() for k, v in out.items()})
 
 
-def infer_golden(R, out_dir, sd):
+def infer_golden(R, out_dir, sd, name="infer_1img", H=40, W=56, classes=(3, 11), seed0=40, store_stride=1):
+    """contrast_infer.py:49-99 on one synthetic image: the 8 MSF inputs (4 scales x flip, sizes round(H*s) x round(W*s) as
+    voc12/data.py:100-121 makes them), the reference Net, and the reference's own post-process text (:75-80, :97-98)."""
     model = R.Net()
     model.load_state_dict(sd)
     model.eval()
-    H, W = 40, 56
     lab = torch.zeros(20)
-    lab[[3, 11]] = 1
+    lab[list(classes)] = 1
     imgs = []
     for si, s in enumerate([0.5, 1.0, 1.5, 2.0]):
         hs, ws = int(np.round(H * s)), int(np.round(W * s))
-        im = synth.synthetic_images(1, (hs, ws), 40 + si)
+        im = synth.synthetic_images(1, (hs, ws), seed0 + si)
         imgs += [im, torch.flip(im, dims=[3])]
     cam_list = []
     for i, img in enumerate(imgs):
@@ -217,15 +218,115 @@ def infer_golden(R, out_dir, sd):
     ns = {"np": np, "cam_list": cam_list, "args": types.SimpleNamespace(out_cam_pred_alpha=0.26)}
     exec(post, ns)
     exec(pred_src, ns)
-    np.savez_compressed(os.path.join(out_dir, "infer_1img.npz"), H=H, W=W, label=lab.numpy(),
-                        norm_cam=ns["norm_cam"].astype(np.float32), pred=ns["pred"].astype(np.uint8))
-    print("wrote infer_1img", ns["norm_cam"].shape, np.bincount(ns["pred"].reshape(-1)))
+    norm_cam = ns["norm_cam"].astype(np.float32)
+    extra = {}
+    if name == "infer_1img":
+        extra["norm_cam"] = norm_cam                                 # (round-1 layout: all 20 planes)
+    else:                                                            # present planes only (the others are the constant -1), optionally strided
+        extra["classes"] = np.array(sorted(classes))
+        extra["norm_cam_present"] = norm_cam[sorted(classes)][:, ::store_stride, ::store_stride].copy()
+        extra["store_stride"] = store_stride
+        extra["absent_value"] = np.array([norm_cam[c].min() for c in range(20) if c not in classes] + [norm_cam[[c for c in range(20) if c not in classes][0]].max()])
+        extra["sums"] = norm_cam[sorted(classes)].astype(np.float64).sum(axis=(1, 2))
+    np.savez_compressed(os.path.join(out_dir, name + ".npz"), H=H, W=W, label=lab.numpy(), seed0=seed0,
+                        pred=ns["pred"].astype(np.uint8), **extra)
+    print("wrote", name, norm_cam.shape, np.bincount(ns["pred"].reshape(-1)))
+
+
+def multistep_golden(R, visualization, torchutils, out_dir, name, n, size, seed, sd, py_seed, steps, lr, max_step):
+    """`steps` consecutive iterations of the reference loop (contrast_train.py:128-399): its loop-body text, backward, and its
+    own PolyOptimizer built as :90-96 builds it — pins the momentum buffer, the poly LR and the weight update end to end."""
+    model = R.Net()
+    model.load_state_dict(sd)
+    groups = model.get_parameter_groups()                            # before .train(), as contrast_train.py:90
+    opt = torchutils.PolyOptimizer([
+        {"params": groups[0], "lr": lr, "weight_decay": 5e-4},
+        {"params": groups[1], "lr": 2 * lr, "weight_decay": 0},
+        {"params": groups[2], "lr": 10 * lr, "weight_decay": 5e-4},
+        {"params": groups[3], "lr": 20 * lr, "weight_decay": 0}], lr=lr, weight_decay=5e-4, max_step=max_step)
+    model.train()
+    masks = []
+    for s_ in range(steps):
+        masks += [synth.synthetic_dropout_masks(n, (seed + s_) * 2 + 0), synth.synthetic_dropout_masks(n, (seed + s_) * 2 + 1)]
+    install_masks(model, masks)
+    helpers, body = body_source()
+    random.seed(py_seed)
+    out = {}
+    keys = ["loss", "loss_cls", "loss_er", "loss_ecr", "loss_nce", "loss_intra_nce", "loss_cross_nce", "loss_cross_nce2"]
+    for s_ in range(steps):
+        img = synth.synthetic_images(n, size, seed + s_)
+        lab = synth.synthetic_labels(n, seed + s_)
+        ns = {"torch": torch, "F": F, "np": np, "random": random, "visualization": visualization,
+              "model": model, "pack": (None, img, lab), "args": types.SimpleNamespace(bg_threshold=0.20)}
+        exec(helpers, ns)
+        exec(body, ns)
+        opt.zero_grad()                                              # contrast_train.py:397-399
+        ns["loss"].backward()
+        opt.step()
+        for k in keys:
+            out[f"s{s_}/{k}"] = np.array(float(ns[k].detach()))
+        print(name, "step", s_, {k: round(float(ns[k].detach()), 6) for k in keys}, "lr", [g_["lr"] for g_ in opt.param_groups])
+    params = dict(model.named_parameters())
+    for k in GRAD_KEYS:
+        flat = params[k].detach().reshape(-1)
+        stepv = max(1, flat.numel() // 4096)
+        out["wslice/" + k] = flat[::stepv][:4096].numpy().copy()
+        out["wnorm/" + k] = np.array(params[k].detach().double().norm().item())
+    np.savez_compressed(os.path.join(out_dir, name + ".npz"), n=n, size=size, seed=seed, py_seed=py_seed, steps=steps, lr=lr,
+                        max_step=max_step, lr_final=np.array([g_["lr"] for g_ in opt.param_groups]), **out)
+    print("wrote", name)
+
+
+def eval_golden(out_dir):
+    """The reference's evaluator itself (eval.py:13-86, imported from /root/reference) on a small synthetic prediction / ground
+    truth set: stores the inputs and its IoU tables for `png` predictions and for `npy` CAM dictionaries at three thresholds."""
+    import importlib.util
+    import tempfile
+    import PIL.Image
+    spec = importlib.util.spec_from_file_location("ref_eval", os.path.join(REF, "eval.py"))
+    ref_eval = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_eval)
+    rng = np.random.default_rng(3)
+    names = ["2007_%06d" % (32 + 7 * i) for i in range(6)]
+    tmp = tempfile.mkdtemp()
+    pd_, gd, nd = (os.path.join(tmp, x) for x in ("pred", "gt", "npy"))
+    for d in (pd_, gd, nd):
+        os.makedirs(d)
+    out = {"names": np.array(names)}
+    for i, nm in enumerate(names):
+        h, w = 23 + 5 * i, 31 + 3 * i
+        cls = rng.choice(np.arange(1, 21), size=1 + i % 3, replace=False)
+        gt = np.zeros((h, w), np.uint8)
+        for c in cls:
+            y0, x0 = rng.integers(0, h // 2), rng.integers(0, w // 2)
+            gt[y0:y0 + h // 2, x0:x0 + w // 2] = c
+        gt[rng.random((h, w)) < 0.05] = 255                          # ignore label
+        pred = gt.copy()
+        pred[pred == 255] = 0
+        flip = rng.random((h, w)) < 0.2
+        pred[flip] = rng.choice(np.concatenate([[0], cls, [int(rng.integers(1, 21))]]), size=int(flip.sum()))
+        cams = {int(c) - 1: (rng.random((h, w)).astype(np.float32) * (0.3 + 0.7 * (gt == c))).astype(np.float32) for c in cls}
+        PIL.Image.fromarray(gt).save(os.path.join(gd, nm + ".png"))
+        PIL.Image.fromarray(pred.astype(np.uint8)).save(os.path.join(pd_, nm + ".png"))
+        np.save(os.path.join(nd, nm + ".npy"), cams)
+        out[f"gt/{nm}"] = gt
+        out[f"pred/{nm}"] = pred.astype(np.uint8)
+        out[f"camkeys/{nm}"] = np.array(sorted(cams))
+        out[f"cams/{nm}"] = np.stack([cams[k] for k in sorted(cams)])
+    cats = ref_eval.categories + ["mIoU"]
+    res = ref_eval.do_python_eval(pd_, gd, names, 21, "png", 1.0)
+    out["iou/png"] = np.array([res[c] for c in cats])
+    for t in (0.1, 0.26, 0.5):
+        res = ref_eval.do_python_eval(nd, gd, names, 21, "npy", t)
+        out["iou/npy_t%.2f" % t] = np.array([res[c] for c in cats])
+    np.savez_compressed(os.path.join(out_dir, "eval_ref.npz"), **out)
+    print("wrote eval_ref", {k: float(v[-1]) for k, v in out.items() if k.startswith("iou/")})
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
-    ap.add_argument("--only", default="")
+    ap.add_argument("--only", default="", help="comma list of: fwd,step,step_edge,sgd,topk,infer,infer_ms,infer_full,multistep,eval")
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     torch.manual_seed(0)
@@ -249,6 +350,16 @@ def main():
         topk_pattern_golden(a.out)
     if "infer" in todo:
         infer_golden(R, a.out, sd)
+    if "infer_ms" in todo:                           # odd, non-trivial sizes + BASELINE config 5's real geometry (375 x 500: inputs up to 750 x 1000)
+        infer_golden(R, a.out, sd, "infer_125x94", 125, 94, (0, 7, 14), seed0=50)
+        infer_golden(R, a.out, sd, "infer_188x250", 188, 250, (5,), seed0=60)
+    if "infer_full" in todo:
+        infer_golden(R, a.out, sd, "infer_375x500", 375, 500, (1, 16), seed0=70, store_stride=3)
+    if "multistep" in todo:
+        multistep_golden(R, visualization, torchutils, a.out, "step_S128_N3_x3", 3, 128, 51, sd, py_seed=9, steps=3,
+                         lr=float(os.environ.get("WSEG_GOLDEN_LR", "3e-6")), max_step=10)
+    if "eval" in todo:
+        eval_golden(a.out)
 
 
 if __name__ == "__main__":

@@ -27,6 +27,15 @@ def _bn(x, sd, p):
                         sd[p + ".weight"], sd[p + ".bias"], False, 0.0, BN_EPS)
 
 
+def _relu(x, gates, key):
+    """ReLU — or, when `gates` holds a 0/1 tensor for this site, `x * gate`: the ReLU decision of ANOTHER implementation
+    injected into this one (tests/test_gpu_loss.py uses it to show that two f32 implementations whose weight gradients differ
+    only differ in which near-zero pre-activations they let through)."""
+    if gates is None or key not in gates:
+        return F.relu(x)
+    return x * gates[key]
+
+
 def _drop(x, masks, key):
     if masks is None:
         return x
@@ -34,47 +43,47 @@ def _drop(x, masks, key):
     return x * m.view(m.shape[0], m.shape[1], 1, 1)
 
 
-def res_block(x, sd, name, stride, first_dilation, dilation):
+def res_block(x, sd, name, stride, first_dilation, dilation, gates=None):
     """ResBlock.forward — network/resnet38d.py:27-49. Returns (out, x_bn_relu)."""
-    t = F.relu(_bn(x, sd, name + ".bn_branch2a"))
+    t = _relu(_bn(x, sd, name + ".bn_branch2a"), gates, name + ".t")
     if (name + ".conv_branch1.weight") in sd:
         branch1 = F.conv2d(t, sd[name + ".conv_branch1.weight"], None, stride)
     else:
         branch1 = x
     y = F.conv2d(t, sd[name + ".conv_branch2a.weight"], None, stride, first_dilation, first_dilation)
-    y = F.relu(_bn(y, sd, name + ".bn_branch2b1"))
+    y = _relu(_bn(y, sd, name + ".bn_branch2b1"), gates, name + ".v")
     y = F.conv2d(y, sd[name + ".conv_branch2b1.weight"], None, 1, dilation, dilation)
     return branch1 + y, t
 
 
-def bot_block(x, sd, name, stride, dilation, masks):
+def bot_block(x, sd, name, stride, dilation, masks, gates=None):
     """ResBlock_bot.forward — network/resnet38d.py:74-99. Returns (out, x_bn_relu)."""
-    t = F.relu(_bn(x, sd, name + ".bn_branch2a"))
+    t = _relu(_bn(x, sd, name + ".bn_branch2a"), gates, name + ".t")
     branch1 = F.conv2d(t, sd[name + ".conv_branch1.weight"], None, stride)
     y = F.conv2d(t, sd[name + ".conv_branch2a.weight"], None, stride)
-    y = F.relu(_bn(y, sd, name + ".bn_branch2b1"))
+    y = _relu(_bn(y, sd, name + ".bn_branch2b1"), gates, name + ".v1")
     y = _drop(y, masks, name + ".dropout_2b1")
     y = F.conv2d(y, sd[name + ".conv_branch2b1.weight"], None, 1, dilation, dilation)
-    y = F.relu(_bn(y, sd, name + ".bn_branch2b2"))
+    y = _relu(_bn(y, sd, name + ".bn_branch2b2"), gates, name + ".v2")
     y = _drop(y, masks, name + ".dropout_2b2")
     y = F.conv2d(y, sd[name + ".conv_branch2b2.weight"], None, 1)
     return branch1 + y, t
 
 
-def backbone(x, sd, masks=None):
+def backbone(x, sd, masks=None, gates=None):
     """forward_as_dict — network/resnet38d.py:160-189. Returns dict conv4, conv5, conv6."""
     x = F.conv2d(x, sd["conv1a.weight"], None, 1, 1)
     taps = {}
     for name, kind, stride, fd, d in _BLOCKS:
         if kind == "res":
-            x, t = res_block(x, sd, name, stride, fd, d)
+            x, t = res_block(x, sd, name, stride, fd, d, gates)
         else:
-            x, t = bot_block(x, sd, name, stride, d, masks)
+            x, t = bot_block(x, sd, name, stride, d, masks, gates)
         if name == "b5":
             taps["conv4"] = t
         if name == "b6":
             taps["conv5"] = t
-    taps["conv6"] = F.relu(_bn(x, sd, "bn7"))
+    taps["conv6"] = _relu(_bn(x, sd, "bn7"), gates, "conv6")
     return taps
 
 
@@ -103,18 +112,18 @@ def cam_normalize(cam):
     return cam_d_norm
 
 
-def net_forward(x, sd, masks=None, return_lowres=False):
+def net_forward(x, sd, masks=None, return_lowres=False, gates=None):
     """Net.forward — network/resnet38_contrast.py:31-61.
     Returns (cam, cam_rv, f_proj, cam_rv_down) [+ (cam_lowres,) when return_lowres]."""
     N, C, H, W = x.size()
-    d = backbone(x, sd, masks)
+    d = backbone(x, sd, masks, gates)
     fea = _drop(d["conv6"], masks, "dropout7")
-    f_proj = F.relu(F.conv2d(fea, sd["fc_proj.weight"]))
+    f_proj = _relu(F.conv2d(fea, sd["fc_proj.weight"]), gates, "f_proj")
     cam_low = F.conv2d(fea, sd["fc8.weight"])
     n, c, h, w = cam_low.size()
     cam_d_norm = cam_normalize(cam_low)
-    f8_3 = F.relu(F.conv2d(d["conv4"].detach(), sd["f8_3.weight"]))
-    f8_4 = F.relu(F.conv2d(d["conv5"].detach(), sd["f8_4.weight"]))
+    f8_3 = _relu(F.conv2d(d["conv4"].detach(), sd["f8_3.weight"]), gates, "f8_3")
+    f8_4 = _relu(F.conv2d(d["conv5"].detach(), sd["f8_4.weight"]), gates, "f8_4")
     x_s = F.interpolate(x, (h, w), mode="bilinear", align_corners=True)
     f = torch.cat([x_s, f8_3, f8_4], dim=1)
     cam_rv_down = pcm(cam_d_norm, f, sd)

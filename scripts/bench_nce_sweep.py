@@ -1,7 +1,12 @@
-"""Pixel-to-prototype similarity + InfoNCE kernels (csrc/loss.hip: nce_sims, nce_loss_grad): time and achieved
-HBM bandwidth at the reference shape (P = 4096) and a scaled sweep that shows the asymptotic rate.
-Algorithmic bytes:  nce_sims      reads P*128*4 (features), writes P*128*4 (fn) + P*4 (norm) + 2*P*21*4 (similarities)
-                    nce_loss_grad reads P*128*4 (fn) + 2*P*21*4 + P*(4+4+4+4), writes P*128*4 (dF)   (+ 2*21*128*4 prototypes each)"""
+"""Pixel-to-prototype similarity + InfoNCE (contrast_train.py:245-334): time and achieved HBM bandwidth at the reference shape
+(P = 4096 pixels per view, D = 128, C = 21) and a scaled sweep that shows the asymptotic rate.
+
+Bandwidth is ALGORITHMIC bytes / time, per launch, both views in one launch (2P pixels):
+  nce_records  (forward half: similarities -> hard-pixel records)   P*(128*4 features + 4 label + 4 key)  read, P*12 written  = 532 B / pixel
+  nce_fused    (similarities + 3 InfoNCE terms + gradient)          P*(128*4 + 4 + 4 + 4) read, P*128*4 dF written           = 1036 B / pixel
+  (+ 2 x 21 x 128 x 4 B of prototypes per view, negligible)
+The unfused reference formulation (nce_sims + nce_loss_grad: normalised features and [P,21] similarity rows written to HBM and re-read)
+is timed beside it and charged the SAME algorithmic bytes (1036 B / pixel for the pair), so the two columns compare like for like."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -14,16 +19,26 @@ def timeit(fn, iters):
     for _ in range(iters): fn()
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / iters * 1e3     # us
-print(f"{'P':>9s} {'sims us':>9s} {'GB/s':>8s} {'%8TB/s':>7s} | {'loss+grad us':>12s} {'GB/s':>8s} {'%8TB/s':>7s}")
+print(f"{'P/view':>9s} | {'records us':>10s} {'GB/s':>8s} {'%8TB/s':>7s} | {'fused us':>9s} {'GB/s':>8s} {'%8TB/s':>7s} | {'unfused sims+grad us':>20s} {'GB/s':>8s} {'%8TB/s':>7s}")
 for lg in (12, 14, 16, 18, 20, 22):
     P = 1 << lg
-    F = torch.randn(P, 128, device=dev); pa = torch.nn.functional.normalize(torch.randn(21, 128, device=dev), dim=1); pb = torch.nn.functional.normalize(torch.randn(21, 128, device=dev), dim=1)
-    fn = torch.empty_like(F); nrm = torch.empty(P, device=dev); So = torch.empty(P, 21, device=dev); St = torch.empty(P, 21, device=dev)
-    y = torch.randint(0, 21, (P,), device=dev, dtype=torch.int32); y2 = torch.randint(0, 21, (P,), device=dev, dtype=torch.int32)
-    w = torch.rand(P, device=dev) / P; dF = torch.empty_like(F); sums = torch.zeros(3, device=dev)
+    V = []
+    for _ in range(2):
+        F = torch.randn(P, 128, device=dev)
+        V.append(dict(F=F, p=torch.nn.functional.normalize(torch.randn(21, 128, device=dev), dim=1), y=torch.randint(0, 21, (P,), device=dev, dtype=torch.int32),
+                      w=torch.rand(P, device=dev) / P, dF=torch.empty_like(F), rkey=torch.rand(P, device=dev), rec=torch.empty(3, P, device=dev),
+                      fn=torch.empty_like(F), nrm=torch.empty(P, device=dev), So=torch.empty(P, 21, device=dev), St=torch.empty(P, 21, device=dev)))
+    sums = torch.zeros(3, device=dev)
+    rec_views = [dict(F=v["F"], p_own=v["p"], y_own=v["y"], rkey=v["rkey"], rec=v["rec"]) for v in V]
+    fus_views = [dict(F=v["F"], p_own=v["p"], p_oth=o["p"], y_own=v["y"], y_oth=o["y"], w_intra=v["w"], dF=v["dF"]) for v, o in ((V[0], V[1]), (V[1], V[0]))]
     it = 200 if lg <= 16 else 20
-    t1 = timeit(lambda: L.nce_sims(F, pa, pb, fn, nrm, So, St, P), it)
-    t2 = timeit(lambda: L.nce_loss_grad(fn, nrm, So, St, y, y2, w, pa, pb, dF, sums, P, 0.1 / (2 * P), 0.05), it)
-    b1 = P * 128 * 4 * 2 + P * 4 + 2 * P * 21 * 4 + 2 * 21 * 128 * 4
-    b2 = P * 128 * 4 * 2 + 2 * P * 21 * 4 + P * 16 + 2 * 21 * 128 * 4
-    print(f"{P:9d} {t1:9.2f} {b1/t1/1e3:8.1f} {b1/t1/1e3/8000*100:6.1f}% | {t2:12.2f} {b2/t2/1e3:8.1f} {b2/t2/1e3/8000*100:6.1f}%", flush=True)
+    t0 = timeit(lambda: L.nce_records(rec_views, P), it)
+    t1 = timeit(lambda: L.nce_fused(fus_views, P, 0.1 / (2 * P), 0.05, sums), it)
+    def unfused():
+        for v, o in ((V[0], V[1]), (V[1], V[0])):
+            L.nce_sims(v["F"], v["p"], o["p"], v["fn"], v["nrm"], v["So"], v["St"], P)
+            L.nce_loss_grad(v["fn"], v["nrm"], v["So"], v["St"], v["y"], o["y"], v["w"], v["p"], o["p"], v["dF"], sums, P, 0.1 / (2 * P), 0.05)
+    t2 = timeit(unfused, it)
+    b0 = 2 * (P * 532 + 21 * 128 * 4)
+    b1 = 2 * (P * 1036 + 2 * 21 * 128 * 4)
+    print(f"{P:9d} | {t0:10.2f} {b0/t0/1e3:8.1f} {b0/t0/1e3/8000*100:6.1f}% | {t1:9.2f} {b1/t1/1e3:8.1f} {b1/t1/1e3/8000*100:6.1f}% | {t2:20.2f} {b1/t2/1e3:8.1f} {b1/t2/1e3/8000*100:6.1f}%", flush=True)

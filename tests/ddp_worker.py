@@ -32,7 +32,7 @@ def run(out_path, n_global, size, world, rank):
     model.train()
     masks = [synth.synthetic_dropout_masks(n_global, 40), synth.synthetic_dropout_masks(n_global, 41)]
     model.set_dropout_masks([{k: v[sl].clone() for k, v in m.items()} for m in masks])
-    tr = Trainer(model, opt, 0.20, random.Random(0), rng_parity=False, loss_impl="hip",
+    tr = Trainer(model, opt, 0.20, random.Random(0), rng_parity=False,
                  bg_topk_idx=torch.arange(32, dtype=torch.int32))
     img = synth.synthetic_images(n_global, size, 9)[sl].cuda()
     lab = synth.synthetic_labels(n_global, 9)[sl].cuda()

@@ -86,6 +86,8 @@ def test_conv_epilogues(dt, OC, bm):
     """fused BN-ReLU-dropout second output (forward) and masked-scale (+residual) epilogue (backward);
     bm=256: the 256x256 phase-pipelined kernel (300 rows = one full + one partial row tile)."""
     from wseg_amd import _lib as L
+    if bm == 258 and not hasattr(L.lib, "wseg_gemm256_probe"):
+        pytest.skip("the 256x128 tile is a development probe (WSEG_PROBES=1 build only)")
     tdt = torch.float32 if dt == "f32" else torch.bfloat16
     N, H, W, IC, k = 2, 15, 10, 64, 3
     dev = "cuda"
@@ -257,10 +259,10 @@ def test_conv256_fwd_dgrad(case):
     y7 = torch.full_like(yg, float("nan"))
     L.conv_igemm(xg, wf, y7, N=N, IH=H, IW=W, IC=IC, OH=OH, OW=OW, OC=OC, KH=k, KW=k, stride=s, dil=d, pad=pad, bm_hint=224)
     np.testing.assert_allclose(y7.float().cpu().numpy(), _nhwc(y.detach()).numpy(), **tol)
-    # the 256 x 128 tile kernel (OC % 128 == 0)
-    y2n = torch.full_like(yg, float("nan"))
-    L.conv_igemm(xg, wf, y2n, N=N, IH=H, IW=W, IC=IC, OH=OH, OW=OW, OC=OC, KH=k, KW=k, stride=s, dil=d, pad=pad, bm_hint=258)
-    np.testing.assert_allclose(y2n.float().cpu().numpy(), _nhwc(y.detach()).numpy(), **tol)
+    if hasattr(L.lib, "wseg_gemm256_probe"):                    # the 256 x 128 tile kernel: development-probe builds only
+        y2n = torch.full_like(yg, float("nan"))
+        L.conv_igemm(xg, wf, y2n, N=N, IH=H, IW=W, IC=IC, OH=OH, OW=OW, OC=OC, KH=k, KW=k, stride=s, dil=d, pad=pad, bm_hint=258)
+        np.testing.assert_allclose(y2n.float().cpu().numpy(), _nhwc(y.detach()).numpy(), **tol)
     # the 512 x 128 tile kernel (four stacked A half-tiles, all 160 KiB of LDS)
     y5 = torch.full_like(yg, float("nan"))
     L.conv_igemm(xg, wf, y5, N=N, IH=H, IW=W, IC=IC, OH=OH, OW=OW, OC=OC, KH=k, KW=k, stride=s, dil=d, pad=pad, bm_hint=259)

@@ -2,7 +2,7 @@
 REFERENCE ITSELF (tests/golden/step_*.npz, see oracle/make_goldens.py): the 8 logged scalars within
 1e-4 (fp32 mode, north-star tolerance) and weight-gradient slices, for both loss back-ends:
   hip  — the hand-written loss kernels (csrc/loss.hip), the product path;
-  aten — the staging path (device-side torch ops behind the drop-in Net.forward 4-tuple)."""
+  aten — the cross-check path (tests/aten_trainer.py: device-side torch ops behind the drop-in Net.forward 4-tuple)."""
 import contextlib
 import io
 import os
@@ -23,6 +23,7 @@ def _trainer(proc_sd, precision, loss_impl, n, seed, py_seed, lr=0.01):
     from wseg_amd.optim import PolyOptimizer
     from wseg_amd.resnet38_contrast import Net
     from wseg_amd.train import Trainer
+    from .aten_trainer import AtenTrainer
     model = Net(precision=precision)
     with contextlib.redirect_stdout(io.StringIO()):
         groups = model.get_parameter_groups()
@@ -33,8 +34,8 @@ def _trainer(proc_sd, precision, loss_impl, n, seed, py_seed, lr=0.01):
     model.cuda()
     model.train()
     model.set_dropout_masks([synth.synthetic_dropout_masks(n, seed * 2 + 0), synth.synthetic_dropout_masks(n, seed * 2 + 1)])
-    tr = Trainer(model, opt, 0.20, random.Random(py_seed), rng_parity=True, loss_impl=loss_impl,
-                 bg_topk_idx=cpu_tie_pattern(n * 256, 32))
+    cls = Trainer if loss_impl == "hip" else AtenTrainer
+    tr = cls(model, opt, 0.20, random.Random(py_seed), rng_parity=True, bg_topk_idx=cpu_tie_pattern(n * 256, 32))
     return model, opt, tr
 
 
@@ -74,116 +75,243 @@ def test_step_matches_reference_fixture(golden_dir, proc_sd, name, loss_impl):
     assert opt.global_step == 1
 
 
-def test_hip_step_bf16_close_to_fp32(proc_sd):
-    """bf16 throughput mode: same step, looser stated tolerance."""
+GRAD_KEYS = ["fc8.weight", "fc_proj.weight", "f9.weight", "f8_3.weight", "f8_4.weight", "b7.conv_branch2b1.weight",
+             "b7.conv_branch1.weight", "b6.conv_branch2a.weight", "b5.conv_branch2a.weight", "b4.conv_branch2a.weight",
+             "b4.conv_branch1.weight", "b3.conv_branch2a.weight", "b3_1.conv_branch2b1.weight"]
+
+
+def gates_from_ctx(S):
+    """The ReLU decisions the HIP forward took, per view, in the oracle's layout (0/1 float NCHW tensors keyed as oracle/net.py
+    `_relu` keys them) — read off the saved activations of the engine's forward context."""
+    from wseg_amd import arch
+    N, V = S["N"], S["V"]
+    out = [dict() for _ in range(V)]
+
+    def put(key, rows, dims, cols=None):
+        off = 0
+        for vi, (h, w) in enumerate(dims):
+            r = rows[off:off + N * h * w]
+            off += N * h * w
+            if cols is not None:
+                r = r[:, cols[0]:cols[1]]
+            out[vi][key] = (r.float() != 0).view(N, h, w, -1).permute(0, 3, 1, 2).float().cpu()
+
+    for b in arch.BLOCKS:
+        name = b[0]
+        din, dout = S["dims"][name]
+        for k, dims in (("t", din), ("v", dout), ("v1", dout), ("v2", dout)):
+            if k in S[name]:
+                put(f"{name}.{k}", S[name][k], dims)
+    put("conv6", S["fea"], S["hdims"])
+    put("f_proj", S["head"], S["hdims"], (0, 128))
+    put("f8_3", S["feat"], S["hdims"], (0, 64))
+    put("f8_4", S["feat"], S["hdims"], (64, 192))
+    return out
+
+
+def test_edge_fixture_gradients_under_the_hip_paths_relu_decisions(golden_dir, proc_sd):
+    """Why the edge fixture's backbone gradients are held to 5e-2 against the reference and not 2e-3: its all-twenty-classes
+    image puts ReLU pre-activations within f32 summation noise of zero under large gradients, and which of them pass depends on
+    the summation order (scripts/relu_near_ties.py).  Demonstrated here rather than argued: the CPU oracle re-run with the HIP
+    path's OWN ReLU decisions injected (every backbone / head ReLU site, both views) must reproduce the HIP gradients at the
+    ordinary 2e-3 bar for all 13 fixture keys — so the only difference between the two implementations is which near-zero
+    pre-activations they let through, not the arithmetic."""
+    from oracle import loss as oloss
+    from oracle import net as onet
     from wseg_amd import synth
-    n, size, seed = 2, 160, 21
-    out = {}
-    for prec in ("fp32", "bf16"):
-        model, opt, tr = _trainer(proc_sd, prec, "hip", n, seed, 7, lr=0.0)
-        out[prec] = tr.step(synth.synthetic_images(n, size, seed).cuda(), synth.synthetic_labels(n, seed).cuda())
-    for k in ("loss", "loss_cls", "loss_er", "loss_ecr", "loss_nce"):
-        a, b = float(out["bf16"][k]), float(out["fp32"][k])
-        assert abs(a - b) <= 0.08 * max(1.0, abs(b)), (k, a, b)
+    name = "step_edge_S64_N3"
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    n, size, seed, py_seed = int(g["n"]), int(g["size"]), int(g["seed"]), int(g["py_seed"])
+    model, opt, tr = _trainer(proc_sd, "fp32", "hip", n, seed, py_seed)
+    model._engine.capture_ctx = True
+    lab = torch.from_numpy(g["label"])
+    img = synth.synthetic_images(n, size, seed)
+    got = tr.step(img.cuda(), lab.cuda())
+    gates = gates_from_ctx(model._engine.last_ctx)
+    model._engine.capture_ctx, model._engine.last_ctx = False, None
+    sd = {k: v.clone() for k, v in proc_sd.items()}
+    for k in onet.trainable_keys(sd):
+        sd[k].requires_grad_(True)
+    ref = oloss.train_step(img, lab, sd, synth.synthetic_dropout_masks(n, seed * 2), synth.synthetic_dropout_masks(n, seed * 2 + 1),
+                           0.20, random.Random(py_seed), gates1=gates[0], gates2=gates[1])
+    ref["loss"].backward()
+    for k in SCALARS:
+        assert abs(float(got[k]) - float(ref[k])) <= 1e-4 * max(1.0, abs(float(ref[k]))), (k, float(got[k]), float(ref[k]))
+    params = dict(model.named_parameters())
+    flipped = 0
+    for k in GRAD_KEYS:
+        a = params[k].grad.detach().cpu().reshape(-1)
+        b = sd[k].grad.reshape(-1)
+        scale = float(b.abs().max()) + 1e-12
+        assert float((a - b).abs().max()) / scale < 2e-3, (k, float((a - b).abs().max()) / scale)
+        assert abs(float(a.double().norm()) - float(b.double().norm())) < 2e-3 * float(b.double().norm()), k
+        fix = g["gslice/" + k]
+        stepv = max(1, a.numel() // 4096)
+        flipped += int(np.abs(a[::stepv][:4096].numpy() - fix).max() / (np.abs(fix).max() + 1e-12) > 2e-3)
+    print(f"edge fixture: {flipped} of {len(GRAD_KEYS)} keys differ from the reference fixture by more than 2e-3 (none from the gate-injected oracle)")
 
 
-def test_fused_sgd_matches_reference_fixture(golden_dir):
-    """wseg_sgd_step against the PolyOptimizer fixture (3 steps, momentum quirk, poly LR)."""
-    from wseg_amd import _lib as L
-    g = np.load(os.path.join(golden_dir, "sgd_3steps.npz"))
-    sizes = [g[f"p{i}_init"].size for i in range(3)]
-    pad = [(-s) % 4 for s in sizes]
-    offs = np.cumsum([0] + [s + p for s, p in zip(sizes, pad)])
-    total = int(offs[-1])
-    p = torch.zeros(total); buf = torch.zeros(total)
-    for i in range(3):
-        p[offs[i]:offs[i] + sizes[i]] = torch.from_numpy(g[f"p{i}_init"].reshape(-1))
-    p, buf = p.cuda(), buf.cuda()
-    lr0 = [0.01, 0.02, 0.1]; wd = [5e-4, 0.0, 5e-4]
-    # parameter 1 has no gradient at step 1 in the fixture (torch skips it: buffer and weight untouched);
-    # emulate with per-segment launches
-    first = [True, True, True]
-    for s in range(3):
-        mult = (1 - s / 10) ** 0.9
-        gflat = torch.zeros(total)
-        for i in range(3):
-            gflat[offs[i]:offs[i] + sizes[i]] = torch.from_numpy(g[f"g{s}_{i}"].reshape(-1))
-        gflat = gflat.cuda()
-        for i in range(3):
-            if s == 1 and i == 1:
-                continue
-            sl = slice(int(offs[i]), int(offs[i + 1]))
-            L.sgd_step(p[sl], gflat[sl], buf[sl], [(0, int(offs[i + 1] - offs[i]), lr0[i] * mult, wd[i])], 5e-4, 1.0, first[i])
-            first[i] = False
-    for i in range(3):
-        got = p[offs[i]:offs[i] + sizes[i]].cpu().numpy()
-        np.testing.assert_allclose(got, g[f"p{i}_final"].reshape(-1), rtol=2e-6, atol=1e-7)
+def _multistep(proc_sd, g, prec, loss_impl="hip"):
+    """The 3-step fixture's protocol on the HIP path; returns ([per-step scalar dict], {key: relative error of the weight
+    DELTA w_after - w_before on the fixture's 4096-sample slice})."""
+    from wseg_amd import synth
+    n, size, seed, py_seed, steps = int(g["n"]), int(g["size"]), int(g["seed"]), int(g["py_seed"]), int(g["steps"])
+    model, opt, tr = _trainer(proc_sd, prec, loss_impl, n, seed, py_seed, lr=float(g["lr"]))
+    opt.max_step = int(g["max_step"])
+    masks = []
+    for s_ in range(steps):
+        masks += [synth.synthetic_dropout_masks(n, (seed + s_) * 2), synth.synthetic_dropout_masks(n, (seed + s_) * 2 + 1)]
+    model.set_dropout_masks(masks)
+    scal = []
+    for s_ in range(steps):
+        got = tr.step(synth.synthetic_images(n, size, seed + s_).cuda(), synth.synthetic_labels(n, seed + s_).cuda())
+        scal.append({k: float(got[k]) for k in SCALARS})
+    assert opt.global_step == steps
+    np.testing.assert_allclose([gr["lr"] for gr in opt.param_groups], g["lr_final"], rtol=1e-12)
+    params = dict(model.named_parameters())
+    dw = {}
+    for key in g.files:
+        if key.startswith("wslice/"):
+            k = key[7:]
+            flat = params[k].detach().cpu().reshape(-1)
+            stepv = max(1, flat.numel() // 4096)
+            w0 = proc_sd[k].reshape(-1)[::stepv][:4096].double().numpy()
+            d_ref = g[key].astype(np.float64) - w0
+            d_got = flat[::stepv][:4096].double().numpy() - w0
+            # at the fixture's lr (3e-6: the largest that keeps the random procedural weights out of dead-ReLU collapse) a backbone
+            # weight moves by a few f32 ulps in three steps, so the delta is quantised: allow one ulp of the weight on top
+            ulp = float(np.spacing(np.abs(g[key]).max().astype(np.float32)))
+            dw[k] = (float(np.abs(d_got - d_ref).max()), float(np.abs(d_ref).max()), ulp)
+    return scal, dw
 
 
-@pytest.mark.parametrize("S,h", [(160, 20), (128, 16), (100, 13)])
-def test_maps_on_the_fly_match_materialised(S, h):
-    """csrc/maps.hip (no [N,21,S,S] tensors) against the materialising kernels of csrc/loss.hip on the same inputs:
-    plane statistics / min-pool values exact up to the resize rounding, forward maps and low-res gradients to 1e-5."""
+def test_three_steps_match_reference_fixture(golden_dir, proc_sd):
+    """contrast_train.py:397-399 + tool/torchutils.py:23-33 end to end, three consecutive iterations of the reference's own loop
+    (oracle/make_goldens.py `multistep_golden`): pins the momentum buffer (first step buf = d, then 5e-4 * buf + d), the poly LR
+    (new images, masks and lr each step), the flat-weight buffer <-> pack refresh between steps.  fp32: the 8 scalars of every
+    step at 1e-4 and the weight DELTA after step 3 at 2e-3 of its maximum."""
+    g = np.load(os.path.join(golden_dir, "step_S128_N3_x3.npz"))
+    scal, dw = _multistep(proc_sd, g, "fp32")
+    for s_ in range(int(g["steps"])):
+        for k in SCALARS:
+            ref = float(g[f"s{s_}/{k}"])
+            assert abs(scal[s_][k] - ref) <= 1e-4 * max(1.0, abs(ref)), (s_, k, scal[s_][k], ref)
+    bad = {k: v for k, v in dw.items() if v[0] > 2e-3 * v[1] + 1.01 * v[2]}       # (error, largest reference delta, one ulp of the weight)
+    assert not bad, bad
+    assert dw["fc8.weight"][1] > 100 * dw["fc8.weight"][2]                          # ... and at least the from-scratch head moves by >> 1 ulp
+
+
+# bf16 (throughput) mode against the REFERENCE's fp32 fixtures.  Measured on an MI355X with scripts/measure_bf16_step.py
+# (profiles/r02_bf16_deviation.json: the three one-step fixtures and the three-step fixture); every bar is 2x the measured worst case.
+#   scalar: measured worst relative deviation over all fixtures and steps -> bar
+BF16_SCALAR_BAR = {"loss": 8.4e-3,            # 4.2e-3
+                   "loss_cls": 4.2e-3,        # 2.1e-3
+                   "loss_er": 1.5e-2,         # 7.2e-3
+                   "loss_ecr": 2.7e-2,        # 1.31e-2
+                   "loss_nce": 2.7e-2,        # 1.31e-2 (step 1 of the three-step fixture)
+                   "loss_intra_nce": 4.0e-2,  # 1.98e-2
+                   "loss_cross_nce": 2.3e-2,  # 1.12e-2
+                   "loss_cross_nce2": 3.0e-2}  # 1.47e-2
+# weight gradients, per key group: (minimum cosine of the 4096-sample slice, maximum |norm ratio - 1|); measured worst in brackets.
+# The PCM branch (f9, f8_3, f8_4) is the outlier: its gradient passes through the CAM gate of resnet38_contrast.py:41-48 (entries below the
+# per-pixel maximum are zeroed — a discontinuous function of the CAM), and bf16 forward noise flips near-ties of that gate.
+BF16_GRAD_BAR = {"fc8.": (0.9996, 0.002),           # [0.99981, 0.0006]
+                 "fc_proj.": (0.961, 0.10),         # [0.98061, 0.0488]
+                 "pcm": (0.50, 0.17),               # [0.75115, 0.0837]
+                 "backbone": (0.966, 0.05)}         # [0.98334, 0.0245]
+
+
+def _bf16_grad_bar(key):
+    if key.startswith(("f9.", "f8_3.", "f8_4.")):
+        return BF16_GRAD_BAR["pcm"]
+    for k in ("fc8.", "fc_proj."):
+        if key.startswith(k):
+            return BF16_GRAD_BAR[k]
+    return BF16_GRAD_BAR["backbone"]
+
+
+@pytest.mark.parametrize("name", ["step_S160_N2", "step_S128_N3", "step_edge_S64_N3"])
+def test_bf16_step_against_reference_fixture(golden_dir, proc_sd, name):
+    """Throughput mode held to per-scalar RELATIVE bars against the reference's own fixtures (the round-1 test allowed 8 % of
+    max(1, |ref|), under which loss_er ~ 0.007 could be wrong by 10x), plus per-key gradient cosine and norm-ratio bars."""
+    from wseg_amd import synth
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    n, size, seed, py_seed = int(g["n"]), int(g["size"]), int(g["seed"]), int(g["py_seed"])
+    model, opt, tr = _trainer(proc_sd, "bf16", "hip", n, seed, py_seed)
+    lab = torch.from_numpy(g["label"]) if "label" in g.files else synth.synthetic_labels(n, seed)
+    got = tr.step(synth.synthetic_images(n, size, seed).cuda(), lab.cuda())
+    for k in SCALARS:
+        ref = float(g["s/" + k])
+        assert abs(float(got[k]) - ref) <= BF16_SCALAR_BAR[k] * abs(ref), (k, float(got[k]), ref)
+    params = dict(model.named_parameters())
+    for key in g.files:
+        if not key.startswith("gslice/"):
+            continue
+        k = key[7:]
+        flat = params[k].grad.detach().cpu().reshape(-1)
+        stepv = max(1, flat.numel() // 4096)
+        a, b = flat[::stepv][:4096].double().numpy(), g[key].astype(np.float64)
+        cos = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-300))
+        ratio = float(params[k].grad.double().norm()) / float(g["gnorm/" + k])
+        cos_min, ratio_max = _bf16_grad_bar(k)
+        assert cos >= cos_min, (k, cos)
+        assert abs(ratio - 1.0) <= ratio_max, (k, ratio)
+
+
+def test_bf16_three_steps_against_reference_fixture(golden_dir, proc_sd):
+    """Three consecutive optimizer steps in throughput mode: the same per-scalar bars at every step (the update itself — SGD on the
+    f32 master weights, bf16 mirror refreshed by the same kernel — is pinned in fp32 by test_three_steps_match_reference_fixture)."""
+    g = np.load(os.path.join(golden_dir, "step_S128_N3_x3.npz"))
+    scal, dw = _multistep(proc_sd, g, "bf16")
+    for s_ in range(int(g["steps"])):
+        for k in SCALARS:
+            ref = float(g[f"s{s_}/{k}"])
+            assert abs(scal[s_][k] - ref) <= BF16_SCALAR_BAR[k] * abs(ref), (s_, k, scal[s_][k], ref)
+
+
+@pytest.mark.parametrize("P", [4096, 1000])
+def test_fused_nce_matches_the_unfused_formulation(P):
+    """csrc/loss.hip nce_records + nce_fused (the product path: both views in one launch, nothing but records / dF written)
+    against the unfused reference formulation nce_sims -> intra_pack -> nce_loss_grad on the same inputs: the records and dF
+    bit for bit (same MFMA arithmetic), the three loss sums up to the order of the float atomics.  P = 1000: row tails."""
     from wseg_amd import _lib as L
     dev = "cuda"
-    N, OS = 3, 128
-    g = torch.Generator().manual_seed(S)
-    low = (torch.rand(N, 21, h, h, generator=g) * 2 - 0.6).to(dev)        # mixed signs (cam); rv maps are >= 0
-    low_rv = torch.rand(N, 21, h, h, generator=g).to(dev)
-    lab = (torch.rand(N, 20, generator=g) < 0.25).float()
-    lab[:, 3] = 1
-    lab = lab.to(dev)
-    npix = S * S
-    f32 = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
-    for lo in (low, low_rv):
-        U = f32(N, 21, S, S)
-        L.resize_planar_fwd(lo, U, N * 21, h, h, S, S, True)
-        st_ref, st = f32(N * 21, 6), f32(N * 21, 6)
-        L.plane_stats(U, st_ref, N * 21, npix)
-        L.up_plane_stats(lo, st, N * 21, h, h, S)
-        assert torch.allclose(st[:, :2], st_ref[:, :2], rtol=5e-6, atol=1e-6)
-        assert torch.allclose(st[:, 2], st_ref[:, 2], rtol=1e-4, atol=1e-2)
-        Uf = U.reshape(N * 21, npix).clamp(min=0)
-        imx, imn = st[:, 3].view(torch.int32).long(), st[:, 4].view(torch.int32).long()
-        assert torch.allclose(Uf.gather(1, imx[:, None])[:, 0], st[:, 0], rtol=5e-6, atol=1e-6)
-        assert torch.allclose(Uf.gather(1, imn[:, None])[:, 0], st[:, 1], rtol=5e-6, atol=1e-6)
-        out_ref, out = f32(N, 21, OS, OS), f32(N, 21, OS, OS)
-        L.norm_resize_forward(U, st_ref, lab, out_ref, N, S, OS)
-        L.up_norm_resize_forward(lo, st, lab, out, N, h, h, S, OS)
-        assert torch.allclose(out, out_ref, rtol=1e-5, atol=1e-5)
-    # min-pool values + the complete backward of the rv map
-    U = f32(N, 21, S, S)
-    L.resize_planar_fwd(low_rv, U, N * 21, h, h, S, S, True)
-    q_ref, q = f32(N, npix), f32(N, npix)
-    a_ref, a = torch.empty(N, npix, device=dev, dtype=torch.uint8), torch.empty(N, npix, device=dev, dtype=torch.uint8)
-    L.rvmin_values(U, lab, q_ref, a_ref, N, npix)
-    L.up_rvmin_values(low_rv, lab, q, a, N, h, h, S)
-    assert torch.allclose(q, q_ref, rtol=5e-6, atol=1e-6)
-    assert float((a != a_ref).float().mean()) < 1e-3                      # arg channel may flip only on rounding ties
-    k = npix // 4
-    res = f32(N, 4)
-    ws = torch.empty(L.select_workspace_bytes(N), device=dev, dtype=torch.uint8)
-    L.select_kth(q, N, npix, k, False, False, True, res, ws)
-    G = (torch.rand(N, 21, OS, OS, generator=g) - 0.5).to(dev)
-    bias = (torch.rand(N * 21, generator=g) - 0.5).to(dev) * 1e-3
-    coef = 0.5 / (k * N)
-    for lo, use_q, use_bias in ((low_rv, True, False), (low, False, True)):
-        U = f32(N, 21, S, S)
-        L.resize_planar_fwd(lo, U, N * 21, h, h, S, S, True)
-        st = f32(N * 21, 6)
-        L.up_plane_stats(lo, st, N * 21, h, h, S)
-        dU = torch.zeros(N, 21, S, S, device=dev)
-        L.norm_resize_backward(G, U, st, lab, dU, N, S, OS)
-        if use_q:
-            L.rvmin_backward(q, a, res, lab, dU, N, npix, k, coef)
-        d_ref, d = f32(N, 21, h, h), f32(N, 21, h, h)
-        L.resize_planar_bwd(dU, d_ref, N * 21, h, h, S, S, True, plane_add=bias if use_bias else None)
-        wv = f32(h)
-        L.resize_adjoint_ones(wv, h, S)
-        L.up_maps_backward(G, lo, st, lab, bias if use_bias else None, wv if use_bias else None, wv if use_bias else None,
-                           q if use_q else None, a if use_q else None, res if use_q else None, k, coef, d, N, h, h, S, OS)
-        scale = float(d_ref.abs().max())
-        assert float((d - d_ref).abs().max()) <= 2e-5 * scale, (float((d - d_ref).abs().max()), scale)
+    g = torch.Generator().manual_seed(P)
+    V = []
+    for i in range(2):
+        F = torch.randn(P, 128, generator=g)
+        F[5] = 0.0                                       # a dead pixel: zero feature row (F.normalize eps path)
+        V.append(dict(F=F.to(dev), p=torch.nn.functional.normalize(torch.randn(21, 128, generator=g), dim=1).to(dev),
+                      y=torch.randint(0, 21, (P,), generator=g, dtype=torch.int32).to(dev),
+                      w=((torch.rand(P, generator=g) < 0.4).float() * torch.rand(P, generator=g) / P).to(dev),
+                      rkey=torch.rand(P, generator=g).to(dev)))
+    cc, ci = 0.1 / (2 * P), 0.05
+    ref_sums = torch.zeros(3, device=dev)
+    for v, o in ((V[0], V[1]), (V[1], V[0])):
+        v["fn"], v["nrm"] = torch.empty(P, 128, device=dev), torch.empty(P, device=dev)
+        v["So"], v["St"] = torch.empty(P, 21, device=dev), torch.empty(P, 21, device=dev)
+        L.nce_sims(v["F"], v["p"], o["p"], v["fn"], v["nrm"], v["So"], v["St"], P)
+        v["rec_ref"] = torch.empty(3, P, device=dev)
+        L.intra_pack(v["y"], v["So"], v["rkey"], v["rec_ref"], P)
+        v["dF_ref"] = torch.empty(P, 128, device=dev)
+        L.nce_loss_grad(v["fn"], v["nrm"], v["So"], v["St"], v["y"], o["y"], v["w"], v["p"], o["p"], v["dF_ref"], ref_sums, P, cc, ci)
+    for v in V:
+        v["rec"], v["dF"] = torch.full((3, P), float("nan"), device=dev), torch.full((P, 128), float("nan"), device=dev)
+    L.nce_records([dict(F=v["F"], p_own=v["p"], y_own=v["y"], rkey=v["rkey"], rec=v["rec"]) for v in V], P)
+    sums = torch.zeros(3, device=dev)
+    L.nce_fused([dict(F=v["F"], p_own=v["p"], p_oth=o["p"], y_own=v["y"], y_oth=o["y"], w_intra=v["w"], dF=v["dF"]) for v, o in ((V[0], V[1]), (V[1], V[0]))],
+                P, cc, ci, sums)
+    for v in V:
+        assert torch.equal(v["rec"].view(torch.int32), v["rec_ref"].view(torch.int32))
+        assert torch.equal(v["dF"], v["dF_ref"])
+        assert torch.isfinite(v["dF"]).all()
+    assert torch.allclose(sums, ref_sums, rtol=2e-6, atol=0), (sums, ref_sums)
+    assert float(ref_sums.abs().min()) > 0
+    # the records feed the sort-based sampler through a leading dimension of 1 exactly as the [P,21] table did through 21
+    w21, w1 = torch.empty(P, device=dev), torch.empty(P, device=dev)
+    L.intra_weights(V[0]["y"], V[0]["So"], V[0]["rkey"], None, w21, P)
+    L.intra_weights(V[0]["y"], V[0]["rec"][1], V[0]["rkey"], None, w1, P, ld_s=1)
+    assert torch.equal(w21, w1)
 
 
 @pytest.mark.parametrize("ranks", [1, 2])

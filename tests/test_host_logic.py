@@ -167,3 +167,116 @@ def test_gradient_buckets_tile_the_flat_buffer():
             if lo <= off < hi:
                 blk = name.split(".")[0]
                 assert blk in done or blk in ("fc_proj", "fc8", "f8_3", "f8_4", "f9"), (trigger, name)
+
+
+def test_eval_matches_the_reference_evaluator(golden_dir, tmp_path, lib):
+    """wseg_amd.eval.do_eval against IoU tables produced by the reference's own eval.py:13-86 (`do_python_eval`, run by
+    oracle/make_goldens.py on the inputs stored in the fixture): png predictions and npy CAM dictionaries at three background
+    thresholds, 255 = ignore, classes missing from an image's dictionary; and both list formats eval.py / voc12 use."""
+    import PIL.Image
+    from wseg_amd import eval as weval
+    g = np.load(os.path.join(golden_dir, "eval_ref.npz"))
+    names = [str(n) for n in g["names"]]
+    for d in ("pred", "gt", "npy"):
+        (tmp_path / d).mkdir()
+    for n in names:
+        PIL.Image.fromarray(g[f"gt/{n}"]).save(tmp_path / "gt" / (n + ".png"))
+        PIL.Image.fromarray(g[f"pred/{n}"]).save(tmp_path / "pred" / (n + ".png"))
+        np.save(tmp_path / "npy" / (n + ".npy"), {int(k): v for k, v in zip(g[f"camkeys/{n}"], g[f"cams/{n}"])}, allow_pickle=True)
+    cats = weval.CATEGORIES + ["mIoU"]
+    res = weval.do_eval(names, str(tmp_path / "pred"), str(tmp_path / "gt"), "png")
+    np.testing.assert_allclose([res[c] for c in cats], g["iou/png"], rtol=0, atol=1e-9)
+    for t in (0.1, 0.26, 0.5):
+        res = weval.do_eval(names, str(tmp_path / "npy"), str(tmp_path / "gt"), "npy", t)
+        np.testing.assert_allclose([res[c] for c in cats], g["iou/npy_t%.2f" % t], rtol=0, atol=1e-9)
+    bare, paths = tmp_path / "bare.txt", tmp_path / "paths.txt"
+    bare.write_text("\n".join(names) + "\n")                                       # ImageSets/Segmentation/train.txt (eval.py:112)
+    paths.write_text("\n".join(f"/JPEGImages/{n}.jpg /SegmentationClassAug/{n}.png" for n in names) + "\n")     # voc12/*.txt
+    for lst in (bare, paths):
+        r = weval.main(["--list", str(lst), "--predict_dir", str(tmp_path / "npy"), "--gt_dir", str(tmp_path / "gt"), "--type", "npy", "--t", "0.26"])
+        assert abs(r["mIoU"] - float(g["iou/npy_t0.26"][-1])) < 1e-9
+
+
+def test_pickled_npy_loader_refuses_foreign_globals(tmp_path):
+    """cls_labels.npy / <name>.npy are pickles (voc12/data.py:40-44, contrast_infer.py:82-90): the loader admits numeric numpy
+    containers only — a file that names any other global is refused before anything from it runs."""
+    import pickle
+    from wseg_amd import data as wdata
+    from wseg_amd.safe_npy import load_pickled_npy
+    good = {"2007_000032": np.arange(20, dtype=np.float32), "2007_000039": np.ones(20, np.float32)}
+    np.save(tmp_path / "good.npy", good, allow_pickle=True)
+    back = load_pickled_npy(str(tmp_path / "good.npy"))
+    assert sorted(back) == sorted(good) and all(np.array_equal(back[k], good[k]) for k in good)
+    assert [v.tolist() for v in wdata.load_labels(str(tmp_path / "good.npy"), ["2007_000039"])] == [[1.0] * 20]
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ("touch " + str(tmp_path / "pwned"),))
+    np.save(tmp_path / "evil.npy", {"x": Evil()}, allow_pickle=True)
+    with pytest.raises(pickle.UnpicklingError):
+        load_pickled_npy(str(tmp_path / "evil.npy"))
+    with pytest.raises(pickle.UnpicklingError):
+        wdata.load_labels(str(tmp_path / "evil.npy"), ["x"])
+    assert not (tmp_path / "pwned").exists()
+    np.save(tmp_path / "plain.npy", np.arange(6).reshape(2, 3))
+    assert load_pickled_npy(str(tmp_path / "plain.npy")).shape == (2, 3)
+
+
+def test_config1_host_pipeline_at_448(tmp_path, lib):
+    """BASELINE config 1's host side at its stated size, without a GPU: 4 synthetic 448 x 448 VOC-format JPEGs -> the training
+    transforms (contrast_train.py:64-75) -> DataLoader batches of 2 -> [2,3,448,448] float32 + [2,20] labels; the reference's
+    step count (len // batch_size * max_epoches, :88); and the training CLI refuses to run without the HIP device (no CPU path)."""
+    import PIL.Image
+    from wseg_amd import contrast_train, data as wdata, synth
+    from wseg_amd.resnet38_contrast import Net
+    root = tmp_path / "VOC2012"
+    (root / "JPEGImages").mkdir(parents=True)
+    names = [f"2007_00000{i}" for i in range(4)]
+    rng = np.random.default_rng(0)
+    for n in names:
+        PIL.Image.fromarray(rng.integers(0, 256, (448, 448, 3), dtype=np.uint8)).save(root / "JPEGImages" / (n + ".jpg"))
+    lst = tmp_path / "list.txt"
+    lst.write_text("\n".join(f"/JPEGImages/{n}.jpg /SegmentationClassAug/{n}.png" for n in names) + "\n")
+    np.save(tmp_path / "cls_labels.npy", {n: synth.synthetic_labels(4, 0)[i].numpy() for i, n in enumerate(names)}, allow_pickle=True)
+    model = Net(precision="fp32")
+    ds = wdata.VOC12ClsDataset(str(lst), str(root), str(tmp_path / "cls_labels.npy"), wdata.train_transform(model, 448))
+    loader = torch.utils.data.DataLoader(ds, batch_size=2, shuffle=False, num_workers=0, drop_last=True)
+    batches = list(loader)
+    assert len(batches) == 2
+    for nm, img, lab in batches:
+        assert tuple(img.shape) == (2, 3, 448, 448) and img.dtype == torch.float32 and tuple(lab.shape) == (2, 20)
+        assert torch.isfinite(img).all() and float(img.abs().max()) < 3.0
+    if not torch.cuda.is_available():
+        with pytest.raises((RuntimeError, AssertionError, SystemExit)):
+            contrast_train.main(["--weights", "procedural", "--batch_size", "2", "--max_epoches", "1", "--train_list", str(lst),
+                                 "--voc12_root", str(root), "--labels", str(tmp_path / "cls_labels.npy"), "--num_workers", "0",
+                                 "--session_name", str(tmp_path / "s")])
+
+
+def test_bench_gpus_flag_starts_that_many_ranks(monkeypatch):
+    """`python bench.py --gpus N` without a launcher must start N ranks as a CHILD process (torch.distributed.run) and hand its
+    return code back; with RANK set it must refuse a world size that differs from --gpus (no one-GPU number labelled N GPUs)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    calls = []
+
+    class R:
+        returncode = 7
+    monkeypatch.setattr(bench.subprocess, "run", lambda cmd, env=None: (calls.append((cmd, env)), R())[1])
+    monkeypatch.delenv("RANK", raising=False)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(bench.sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7 and len(calls) == 1
+    cmd = calls[0][0]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
+    assert calls[0][1]["HSA_ENABLE_IPC_MODE_LEGACY"] == os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "WORLD_SIZE=1" in str(e.value.code) and len(calls) == 1

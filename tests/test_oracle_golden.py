@@ -118,3 +118,65 @@ def test_infer_postprocess(golden_dir, proc_sd):
     np.testing.assert_allclose(norm_cam, g["norm_cam"], rtol=1e-5, atol=1e-6)
     assert (pred == g["pred"]).mean() > 0.999
     assert sorted(cam_dict.keys()) == [3, 11]
+
+
+def test_infer_multiscale_odd_size(golden_dir, proc_sd):
+    """The restatement against the reference's multi-scale fixture at an odd size (125 x 94: feature maps 16 x 12 ... 32 x 24,
+    scales whose rounded sizes are odd); the larger fixtures (188 x 250, 375 x 500) are checked on the GPU only — minutes on CPU."""
+    g = _load(golden_dir, "infer_125x94")
+    H, W, seed0 = int(g["H"]), int(g["W"]), int(g["seed0"])
+    lab = torch.from_numpy(g["label"])
+    imgs = []
+    for si, s in enumerate([0.5, 1.0, 1.5, 2.0]):
+        im = synth.synthetic_images(1, (int(np.round(H * s)), int(np.round(W * s))), seed0 + si)
+        imgs += [im, torch.flip(im, dims=[3])]
+    norm_cam, pred, cam_dict = oinfer.infer_one(imgs, lab, proc_sd, (H, W), 0.26)
+    classes = [int(c) for c in g["classes"]]
+    assert sorted(cam_dict.keys()) == classes
+    st = int(g["store_stride"])
+    np.testing.assert_allclose(norm_cam[classes][:, ::st, ::st], g["norm_cam_present"], rtol=1e-5, atol=1e-6)
+    assert (pred == g["pred"]).mean() > 0.9999
+    absent = [c for c in range(20) if c not in classes]
+    assert np.abs(norm_cam[absent] + 1.0).max() < 1e-6         # a gated class: (0 - 0 - 1e-5) / (0 - 0 + 1e-5)
+
+
+def test_three_consecutive_steps(golden_dir, proc_sd):
+    """oracle train_step + oracle PolySGD over three iterations against the fixture the reference's own loop produced
+    (contrast_train.py:128-399 with tool/torchutils.py:11-33): scalars of every step, weights after step 3."""
+    g = _load(golden_dir, "step_S128_N3_x3")
+    n, size, seed, py_seed, steps, lr = int(g["n"]), int(g["size"]), int(g["seed"]), int(g["py_seed"]), int(g["steps"]), float(g["lr"])
+    sd = {k: v.clone() for k, v in proc_sd.items()}
+    keys = onet.trainable_keys(sd)
+    scratch = ("f8_3.", "f8_4.", "f9.", "fc8.", "fc_proj.")
+    # contrast_train.py:90-96 with Net.get_parameter_groups called BEFORE train(): group 0 holds every conv weight outside the
+    # from-scratch layers (the frozen ones included — they never get a gradient), group 2 the from-scratch ones
+    conv_keys = [k for k, v in sd.items() if v.dim() == 4]
+    g0 = [sd[k] for k in conv_keys if not k.startswith(scratch)]
+    g2 = [sd[k] for k in conv_keys if k.startswith(scratch)]
+    opt = ooptim.PolySGD([{"params": g0, "lr": lr, "weight_decay": 5e-4}, {"params": [], "lr": 2 * lr, "weight_decay": 0},
+                          {"params": g2, "lr": 10 * lr, "weight_decay": 5e-4}, {"params": [], "lr": 20 * lr, "weight_decay": 0}],
+                         lr=lr, weight_decay=5e-4, max_step=int(g["max_step"]))
+    rng = random.Random(py_seed)
+    for s_ in range(steps):
+        for k in keys:
+            sd[k].requires_grad_(True)
+            sd[k].grad = None
+        out = oloss.train_step(synth.synthetic_images(n, size, seed + s_), synth.synthetic_labels(n, seed + s_), sd,
+                               synth.synthetic_dropout_masks(n, (seed + s_) * 2), synth.synthetic_dropout_masks(n, (seed + s_) * 2 + 1), 0.20, rng)
+        out["loss"].backward()
+        for k in ["loss", "loss_cls", "loss_er", "loss_ecr", "loss_nce", "loss_intra_nce", "loss_cross_nce", "loss_cross_nce2"]:
+            ref = float(g[f"s{s_}/{k}"])
+            assert abs(float(out[k]) - ref) <= 5e-6 * max(1.0, abs(ref)), (s_, k, float(out[k]), ref)
+        grads = {id(sd[k]): sd[k].grad for k in keys}
+        for k in keys:
+            sd[k].requires_grad_(False)
+        opt.step(grads)
+    np.testing.assert_allclose([gr["lr"] for gr in opt.groups], g["lr_final"], rtol=1e-12)
+    for key in g.files:
+        if key.startswith("wslice/"):
+            k = key[7:]
+            flat = sd[k].reshape(-1)
+            stepv = max(1, flat.numel() // 4096)
+            w0 = proc_sd[k].reshape(-1)[::stepv][:4096].double().numpy()
+            d_ref, d_got = g[key].astype(np.float64) - w0, flat[::stepv][:4096].double().numpy() - w0
+            assert np.abs(d_got - d_ref).max() <= 1e-3 * np.abs(d_ref).max(), k

@@ -284,11 +284,34 @@ def pseudo_label(R, label20, bg_thr, y, ncam, N, npix): _call("wseg_pseudo_label
 def proto_candidates(ncam, F, tie_idx, cand_val, cand_feat, cand_const, N, npix, K): _call("wseg_proto_candidates", _v(ncam), _v(F), _v(tie_idx), _v(cand_val), _v(cand_feat), _v(cand_const), N, npix, K)
 def proto_merge(cand_val, cand_feat, cand_const, protos, world, K, rank_stride=0): _call("wseg_proto_merge", _v(cand_val), _v(cand_feat), _v(cand_const), _v(protos), world, K, C.c_long(rank_stride))
 def nce_sims(F, p_own, p_oth, fn, nrm, S_own, S_oth, P): _call("wseg_nce_sims", _v(F), _v(p_own), _v(p_oth), _v(fn), _v(nrm), _v(S_own), _v(S_oth), P)
-def intra_weights(y, S_own, rkey, rand_flag, w, P): _call("wseg_intra_weights", _v(y), _v(S_own), _v(rkey), _v(rand_flag), _v(w), P)
+def intra_weights(y, S_own, rkey, rand_flag, w, P, ld_s=21): _call("wseg_intra_weights", _v(y), _v(S_own), ld_s, _v(rkey), _v(rand_flag), _v(w), P)
 def intra_pack(y, S_own, rkey, rec, P): _call("wseg_intra_pack", _v(y), _v(S_own), _v(rkey), _v(rec), P)
 def intra_weights_global(rec, w, P, ranks, own_rank, scale, rank_stride): _call("wseg_intra_weights_global", _v(rec), _v(w), P, ranks, own_rank, _f(scale), C.c_long(rank_stride))
 def nce_loss_grad(fn, nrm, S_own, S_oth, y_own, y_oth, w_intra, p_own, p_oth, dF, sums, P, coef_cross, coef_intra):
     _call("wseg_nce_loss_grad", _v(fn), _v(nrm), _v(S_own), _v(S_oth), _v(y_own), _v(y_oth), _v(w_intra), _v(p_own), _v(p_oth), _v(dF), _v(sums), P, _f(coef_cross), _f(coef_intra))
+
+
+class NceView(C.Structure):
+    _fields_ = [("F", C.c_void_p), ("p_own", C.c_void_p), ("p_oth", C.c_void_p), ("y_own", C.c_void_p), ("y_oth", C.c_void_p),
+                ("w_intra", C.c_void_p), ("rkey", C.c_void_p), ("rec", C.c_void_p), ("dF", C.c_void_p)]
+
+
+def _nce_views(views):
+    arr = (NceView * len(views))()
+    for i, v in enumerate(views):
+        for k, _t in NceView._fields_:
+            setattr(arr[i], k, _ptr(v.get(k)))
+    return arr
+
+
+def nce_records(views, P):
+    """views: list of dicts (F, p_own, y_own, rec[, rkey]) — one launch for all of them."""
+    _call("wseg_nce_records", _nce_views(views), len(views), P)
+
+
+def nce_fused(views, P, coef_cross, coef_intra, sums):
+    """views: list of dicts (F, p_own, p_oth, y_own, y_oth, w_intra, dF) — one launch for all of them."""
+    _call("wseg_nce_fused", _nce_views(views), len(views), P, _f(coef_cross), _f(coef_intra), _v(sums))
 
 
 # ---- SEAM map losses evaluated on the fly from the stride-8 maps (csrc/maps.hip): no [N,21,S,S] tensors
@@ -304,6 +327,8 @@ def up_maps_backward(G, low, stats, label20, plane_bias, wvec_y, wvec_x, q, argc
 
 
 def gemm256_probe(A, B, Cout, M, N, K, variant=0):
+    if not hasattr(lib, "wseg_gemm256_probe"):
+        raise RuntimeError("wseg_gemm256_probe is a development probe: rebuild with `WSEG_PROBES=1 bash wseg_amd/csrc/build.sh`")
     check(lib.wseg_gemm256_probe(_v(A), _v(B), _v(Cout), M, N, K, variant, _s()), "wseg_gemm256_probe")
 
 

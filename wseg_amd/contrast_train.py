@@ -3,8 +3,10 @@
     python -m wseg_amd.contrast_train --weights <ckpt.pth|procedural> [--synthetic N] ...
     torchrun --nproc-per-node 8 --master-addr 127.0.0.1 -m wseg_amd.contrast_train ...   (one process per GPU, RCCL)
 
+`--batch_size` keeps the reference's meaning — the GLOBAL batch (nn.DataParallel splits it over the GPUs, contrast_train.py:80-90,108):
+every rank takes batch_size / world images per step and max_step = (len(dataset) // batch_size) * max_epoches (:88).
 Additive flags only: --labels (path of cls_labels.npy/.npz), --synthetic N (N procedural images instead of
-VOC), --precision, --loss {hip,aten}, --rng_parity.  Logging keeps the reference's line format and its
+VOC), --precision, --rng_parity, --seed (rank r seeds torch with seed + r: Dropout2d masks and hard-pixel keys differ per rank).  Logging keeps the reference's line format and its
 `imps` definition (images, not views, per second; :413-420); tensorboardX is not available offline.
 """
 import argparse
@@ -44,8 +46,8 @@ def main(argv=None):
     parser.add_argument("--labels", default="voc12/cls_labels.npy", type=str)
     parser.add_argument("--synthetic", default=0, type=int)
     parser.add_argument("--precision", default=None, choices=[None, "bf16", "fp32"])
-    parser.add_argument("--loss", default="hip", choices=["hip", "aten"])
     parser.add_argument("--rng_parity", action="store_true")
+    parser.add_argument("--seed", default=0, type=int)
     args = parser.parse_args(argv)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -56,6 +58,11 @@ def main(argv=None):
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
+    if args.batch_size % world != 0:
+        raise SystemExit(f"--batch_size {args.batch_size} is the global batch (reference semantics) and must divide by the {world} ranks")
+    local_batch = args.batch_size // world
+    torch.manual_seed(args.seed + rank)                     # torch's default seed is a constant: without this every rank would draw the
+    np.random.seed(args.seed + rank)                        # same Dropout2d masks and hard-pixel keys for its different images
     os.makedirs(os.path.join('result', args.session_name), exist_ok=True)
     if rank == 0:
         print(vars(args))
@@ -70,10 +77,10 @@ def main(argv=None):
         ds = wdata.VOC12ClsDataset(args.train_list, args.voc12_root, args.labels, wdata.train_transform(model, args.crop_size))
         n_img = len(ds)
         sampler = torch.utils.data.distributed.DistributedSampler(ds, shuffle=True) if world > 1 else None
-        loader = torch.utils.data.DataLoader(ds, batch_size=args.batch_size, shuffle=sampler is None, sampler=sampler,
+        loader = torch.utils.data.DataLoader(ds, batch_size=local_batch, shuffle=sampler is None, sampler=sampler,
                                              num_workers=args.num_workers, pin_memory=True, drop_last=True,
-                                             worker_init_fn=lambda wid: np.random.seed(1 + wid))
-    steps_per_epoch = n_img // (args.batch_size * world)
+                                             worker_init_fn=lambda wid: np.random.seed(args.seed + 1 + wid + 1000 * rank))
+    steps_per_epoch = n_img // args.batch_size
     max_step = steps_per_epoch * args.max_epoches
 
     param_groups = model.get_parameter_groups()
@@ -93,7 +100,7 @@ def main(argv=None):
     model.load_state_dict(weights_dict, strict=False)
     model.cuda(dev)
     model.train()
-    trainer = Trainer(model, optimizer, args.bg_threshold, random.Random(), args.rng_parity, args.loss)
+    trainer = Trainer(model, optimizer, args.bg_threshold, random.Random(args.seed * 1000003 + rank), args.rng_parity)
 
     sums = {k: 0.0 for k in KEYS}
     cnt = 0
@@ -104,8 +111,8 @@ def main(argv=None):
         it = iter(loader) if loader is not None else None
         for itn in range(steps_per_epoch):
             if it is None:
-                img = synth.synthetic_images(args.batch_size, args.crop_size, seed=(ep * steps_per_epoch + itn) * world + rank, device=dev)
-                lab = synth.synthetic_labels(args.batch_size, seed=(ep * steps_per_epoch + itn) * world + rank, device=dev)
+                img = synth.synthetic_images(local_batch, args.crop_size, seed=(ep * steps_per_epoch + itn) * world + rank, device=dev)
+                lab = synth.synthetic_labels(local_batch, seed=(ep * steps_per_epoch + itn) * world + rank, device=dev)
             else:
                 pack = next(it)
                 img, lab = pack[1].cuda(dev, non_blocking=True), pack[2].cuda(dev, non_blocking=True)
@@ -120,7 +127,7 @@ def main(argv=None):
                 print('Iter:%5d/%5d | ' % (optimizer.global_step - 1, max_step),
                       'loss: %.4f | loss_cls: %.4f | loss_er: %.4f | loss_ecr: %.4f | '
                       'loss_nce: %.4f | loss_intra_nce: %.4f | loss_cross_nce: %.4f | loss_cross_nce2: %.4f' % vals,
-                      'imps:%.1f | ' % ((itn + 1) * args.batch_size * world / (time.time() - stage_start)),
+                      'imps:%.1f | ' % ((itn + 1) * args.batch_size / (time.time() - stage_start)),
                       'Fin:%s | ' % time.ctime(int(est_finish)),
                       'lr: %.4f' % (optimizer.param_groups[0]['lr']), flush=True)
                 sums = {k: 0.0 for k in KEYS}

@@ -4,16 +4,20 @@ set -e
 cd "$(dirname "$0")"
 OUT=../libwseg_hip.so
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17"
+# WSEG_PROBES=1: also compile the development probes (gemm256_probe, the 256x128 conv tile, the WSEG_WGRAD_DIAG / zero-page timing
+# diagnostics, which give wrong results by design) — never part of the product library
+if [ "${WSEG_PROBES:-0}" = "1" ]; then FLAGS="$FLAGS -DWSEG_PROBES"; fi
 SRCS=$(ls *.hip)
 mkdir -p _obj
 pids=()
 for f in $SRCS; do
   o=_obj/${f%.hip}.o
-  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ common.h -nt "$o" ] || [ ../../include/wseg_hip.h -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$(cat _obj/.flags 2>/dev/null)" != "$FLAGS" ] || [ common.h -nt "$o" ] || [ ../../include/wseg_hip.h -nt "$o" ]; then
     hipcc $FLAGS -c "$f" -o "$o" &
     pids+=($!)
   fi
 done
 for p in "${pids[@]}"; do wait $p; done
+echo "$FLAGS" > _obj/.flags
 hipcc --offload-arch=gfx950 --hip-link -shared -fPIC _obj/*.o -o $OUT
 echo "built $OUT"

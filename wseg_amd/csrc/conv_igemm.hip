@@ -14,6 +14,14 @@
 #include <algorithm>
 #include "common.h"
 
+#ifdef WSEG_PROBES   // timing diagnostics of probe builds: bm_hint -1 / -2 feed A / B from the zero page (results wrong by design)
+#define WSEG_DIAG_ZERO_A(d) ((d).bm_hint == -1)
+#define WSEG_DIAG_ZERO_B(d) ((d).bm_hint == -2)
+#else
+#define WSEG_DIAG_ZERO_A(d) false
+#define WSEG_DIAG_ZERO_B(d) false
+#endif
+
 namespace {
 
 constexpr int BN = 128, ROWB = 128;                // out-channel rows per tile, bytes of K per LDS row
@@ -365,7 +373,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const Args a) {
     const int r = wid * 32 + i * 8 + srow;         // row inside the B tile
     lch[i] = pch ^ ((r >> 1) & 7);
     const int oc = n0 + r;
-    if (oc < d.OC && d.bm_hint != -2) {                     // (-2: timing diagnostic, B from the zero page)
+    if (oc < d.OC && !WSEG_DIAG_ZERO_B(d)) {
       bptr[i] = Wp + ((size_t)oc * a.taps * d.IC + (size_t)lch[i] * CH) * ES;
       b_inc[i] = ROWB;
     } else {
@@ -387,7 +395,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const Args a) {
         if (d.stride == 1) { iy = ty; ix = tx; }
         else { iy = ty / d.stride; ix = tx / d.stride; ok = ok && (iy * d.stride == ty) && (ix * d.stride == tx); }
       }
-      ok = ok && iy >= 0 && iy < a_H[i] && ix >= 0 && ix < a_W[i] && d.bm_hint != -1;   // (-1: timing diagnostic, A from the zero page)
+      ok = ok && iy >= 0 && iy < a_H[i] && ix >= 0 && ix < a_W[i] && !WSEG_DIAG_ZERO_A(d);
       if (ok) {
         aptr[i] = IN + ((size_t)(a_img[i] + (long)iy * a_W[i] + ix) * d.ld_in + (size_t)lcha[i] * CH) * ES;
         a_inc[i] = ROWB;
@@ -762,6 +770,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const Args a) {
 }
 
 
+#ifdef WSEG_PROBES   // measured dead end, kept for A/B runs only: built by `WSEG_PROBES=1 bash build.sh`
 // ---- 256(M) x 128(N) bf16 phase-pipelined variant: layers with OC = 128 (the frozen 224x224 prefix) and narrow tails.
 // 8 waves as 4(M) x 2(N), wave tile 64 x 64 = 4 x 4 accumulators; LDS = 3 K-tiles x {A0, A1, B} slots of
 // [128 rows][128 B] = 16 KiB each (144 KiB).  A K-tile is 2 phases of 16 MFMAs (32 rows x 64 cols of the wave tile each;
@@ -944,6 +953,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256x128_kernel(const Args a)
   __syncthreads();                                 // every wave is done with the pipeline buffers
   wave_local_epilogue<EPI, 4>(a, smem, wid, lane, m0 + wr * 64, wc * 64, n0, acc);
 }
+#endif  // WSEG_PROBES
 
 
 // ---- 512(M) x 128(N) bf16 phase-pipelined variant for OC = 128 layers (the frozen 224x224 prefix) -----------------------
@@ -1168,7 +1178,9 @@ extern "C" int wseg_conv_igemm(const wseg_conv_desc* d, void* stream) {
   // 256 x 128 phase-pipelined tiles (bm_hint 258, or WSEG_CONV256X128=1 for OC = 128 layers with many pixels).  Measured on
   // the frozen 224x224 prefix (128->128 3x3, K = 1152): 703 vs 700 TF/s for the 128^2 kernel — those layers are bound by
   // their epilogue (18 K-tiles per tile), which two resident workgroups per CU overlap and one cannot; off by default.
+#ifdef WSEG_PROBES
   static const int auto2n = getenv("WSEG_CONV256X128") ? atoi(getenv("WSEG_CONV256X128")) : 0;
+#endif
   // 512 x 128 phase-pipelined tiles for OC = 128 layers with many pixels (259 forces it); fast taps only
   static const int auto512 = getenv("WSEG_CONV512") ? atoi(getenv("WSEG_CONV512")) : 1;   // (0: A/B switch; measured 649 -> 766 TF/s on 128->128 3x3 224^2)
   const bool tall = !big && d->dtype == WSEG_BF16 && d->OC % 128 == 0 && (d->mode == 0 || d->stride == 1) &&
@@ -1184,6 +1196,7 @@ extern "C" int wseg_conv_igemm(const wseg_conv_desc* d, void* stream) {
     WSEG_LAUNCH_CHECK();
     return 0;
   }
+#ifdef WSEG_PROBES
   const bool mid = !big && d->dtype == WSEG_BF16 && d->OC % 128 == 0 &&
                    (d->bm_hint == 258 || (auto2n && d->bm_hint == 0 && d->OC == 128 && (M + 255) / 256 >= 512));
   if (mid) {
@@ -1194,7 +1207,13 @@ extern "C" int wseg_conv_igemm(const wseg_conv_desc* d, void* stream) {
     if (d->epi == 0) hipLaunchKernelGGL(conv_igemm256x128_kernel<0>, dim3(a.nwg), dim3(512), 0, s, a);
     else if (d->epi == 1) hipLaunchKernelGGL(conv_igemm256x128_kernel<1>, dim3(a.nwg), dim3(512), 0, s, a);
     else hipLaunchKernelGGL(conv_igemm256x128_kernel<2>, dim3(a.nwg), dim3(512), 0, s, a);
-  } else if (big) {
+    WSEG_LAUNCH_CHECK();
+    return 0;
+  }
+#else
+  WSEG_CHECK(d->bm_hint != 258, "conv_igemm: bm_hint 258 (256x128 probe tile) needs a -DWSEG_PROBES build");
+#endif
+  if (big) {
     const int ntn128 = a.ntn;
     static const int perm_ok = getenv("WSEG_CONV_PERM") ? atoi(getenv("WSEG_CONV_PERM")) : 1;
     if (perm_ok && d->mode == 1 && d->stride == 2 && d->OH % 2 == 0 && d->OW % 2 == 0 && d->OH2 % 2 == 0 && d->OW2 % 2 == 0 && a.taps <= 9 &&

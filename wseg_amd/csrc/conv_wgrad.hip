@@ -20,6 +20,12 @@
 #include <type_traits>
 #include "common.h"
 
+#ifdef WSEG_PROBES   // WSEG_WGRAD_DIAG timing diagnostics (results wrong by design) exist in probe builds only
+#define WG_DIAG(a) ((a).diag)
+#else
+#define WG_DIAG(a) 0
+#endif
+
 namespace {
 
 // transposed LDS read with a compile-time immediate offset (ds_read_b64_tr_b16: 4 pixels x 16 channels per 16-lane group)
@@ -441,7 +447,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pipe_kernel(const Args a) {
   auto issue_x = [&](int h, int buf) {
     char* dst = smem + slot_off(buf, 2 + h) + wid * 1024;
     if constexpr (UNIT) {
-      const int rem = a.diag >= 4 ? 0 : x_lim - x_m;  // rows of this tile inside its sub-range (diag: X from the zero page)
+      const int rem = WG_DIAG(a) >= 4 ? 0 : x_lim - x_m;  // rows of this tile inside its sub-range (diag: X from the zero page)
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         const char* p = (xin[k] && rrx[k][h] < rem) ? xptr[k] + h * 256 : zsrc;
@@ -469,7 +475,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pipe_kernel(const Args a) {
         for (int k = 0; k < 2; ++k) ybase[k] += jump;
         y_m = b_begin; y_lim = m_end;
       }
-      const int rem = a.diag == 5 ? 0 : y_lim - y_m;
+      const int rem = WG_DIAG(a) == 5 ? 0 : y_lim - y_m;
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         const char* p = rry[k][h] < rem ? ybase[k] + h * 256 : zsrc;
@@ -484,7 +490,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pipe_kernel(const Args a) {
     }
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-      const char* p = (my[k] < m_end && yok[k][h] && a.diag != 5) ? ybase[k] + h * 256 : zsrc;
+      const char* p = (my[k] < m_end && yok[k][h] && WG_DIAG(a) != 5) ? ybase[k] + h * 256 : zsrc;
       glds16(p, dst + k * 8192);
     }
     if (h == 1) {
@@ -716,8 +722,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pipe_kernel(const Args a) {
       const int oc = oc0 + ps * EPI_ROWS + row, ic = ic0 + col;
       if (oc < d.OC_dw && ic < d.IC_dw) {
         float* dst = &d.dw[(size_t)oc * row_stride + (size_t)tap * d.IC_dw + ic];
-        if (a.diag == 0) atomicAdd(dst, img[row * EPI_LD + col]);
-        else if (a.diag == 2) *dst = img[row * EPI_LD + col];       // (timing diagnostics only: plain store / nothing)
+        if (WG_DIAG(a) == 0) atomicAdd(dst, img[row * EPI_LD + col]);
+        else if (WG_DIAG(a) == 2) *dst = img[row * EPI_LD + col];       // (timing diagnostics only: plain store / nothing)
       }
     }
     __syncthreads();
@@ -775,8 +781,12 @@ extern "C" int wseg_conv_wgrad(const wseg_wgrad_desc* d, void* stream) {
   a.q64_1 = 64 / d->OW; a.r64_1 = 64 % d->OW;
   a.q64_2 = d->OH2 ? 64 / d->OW2 : 0; a.r64_2 = d->OH2 ? 64 % d->OW2 : 0;
   a.simple_adv = (a.q64_1 + 1 <= d->OH) && (d->OH2 == 0 || a.q64_2 + 1 <= d->OH2);
+#ifdef WSEG_PROBES
   static const int diag = getenv("WSEG_WGRAD_DIAG") ? atoi(getenv("WSEG_WGRAD_DIAG")) : 0;
   a.diag = diag;
+#else
+  a.diag = 0;
+#endif
   static const int wave_epi = getenv("WSEG_WGRAD_EPI") ? atoi(getenv("WSEG_WGRAD_EPI")) : 1;   // (same-box A/B: 12.64 vs 12.73 ms/step)
   a.wave_epi = wave_epi;
   static const int stagger = getenv("WSEG_WGRAD_STAGGER") ? atoi(getenv("WSEG_WGRAD_STAGGER")) : 2;   // (2 measured best: 14.06 vs 14.85 / 15.9 ms/step) 0/1: 4 phases lock-step / ping-pong (1 measured slower: 17.1 vs 14.8 ms/step); 2/3: 2 phases lock-step / ping-pong

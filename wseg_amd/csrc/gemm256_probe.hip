@@ -9,6 +9,7 @@
 //     p1(u): A0(u+1)   p2(u): A1(u+1)   p3(u): B0(u+2)   p4(u): B1(u+2)
 // so LDS-DMA runs 1.5 tiles ahead with only two tile buffers; the only wait is a counted
 // s_waitcnt vmcnt(4) in p4 (B0/B1(u+2) may stay in flight).  Fragment reads per phase: 12, 4, 8, 0.
+#ifdef WSEG_PROBES   // development probe: not part of the product library (build with WSEG_PROBES=1 bash build.sh)
 #include "common.h"
 
 namespace {
@@ -137,3 +138,4 @@ extern "C" int wseg_gemm256_probe(const void* A, const void* B, float* C, int M,
   WSEG_LAUNCH_CHECK();
   return 0;
 }
+#endif  // WSEG_PROBES

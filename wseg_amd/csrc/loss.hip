@@ -589,7 +589,7 @@ __global__ __launch_bounds__(256) void nce_sims_kernel(const float* __restrict__
 
 // ---- hard pixel sampling weights (contrast_train.py:302-331), single workgroup, P <= 8192.
 //   key1 = S_own[p][y_p] (similarity order), key2 = random key or host flag.  w[p] = (#selections)/(2*half*C).
-__global__ __launch_bounds__(1024) void intra_weights_kernel(const int* __restrict__ y, const float* __restrict__ S_own, const float* __restrict__ rkey,
+__global__ __launch_bounds__(1024) void intra_weights_kernel(const int* __restrict__ y, const float* __restrict__ S_own, int ld_s, const float* __restrict__ rkey,
                                                              const unsigned char* __restrict__ rand_flag, float* __restrict__ w, int P) {
   extern __shared__ unsigned long long keys[];              // [P2] sort buffer
   __shared__ int cnt[21], start[21], nclass;
@@ -610,7 +610,7 @@ __global__ __launch_bounds__(1024) void intra_weights_kernel(const int* __restri
     for (int i = tid; i < P2; i += 1024) {
       unsigned long long k = ~0ull;
       if (i < P) {
-        const float f = pass == 0 ? S_own[(size_t)i * 21 + y[i]] : rkey[i];
+        const float f = pass == 0 ? (ld_s == 1 ? S_own[i] : S_own[(size_t)i * ld_s + y[i]]) : rkey[i];
         k = ((unsigned long long)y[i] << 56) | ((unsigned long long)f2key(f) << 24) | (unsigned long long)i;   // i < 2^24
       }
       keys[i] = k;
@@ -843,6 +843,215 @@ __global__ __launch_bounds__(256) void nce_loss_grad_kernel(const float* __restr
   }
 }
 
+
+// ============================================================================================================================
+// Fused pixel-to-prototype contrast (contrast_train.py:245-334): the product path.  Two launches per step for BOTH views:
+//   nce_records_kernel  F, prototypes, labels            -> per-pixel record {label, similarity to its own class, random key}
+//                                                           (the inputs of the hard-pixel sampling)            520 B / pixel
+//   nce_fused_kernel    F, both prototype sets, labels,
+//                       hard-pixel weights                -> dF and the three loss sums                         1.03 KB / pixel
+// The features are read once per launch and nothing but dF / 12-byte records is written: the normalised features and the
+// [P,21] similarity rows of nce_sims / nce_loss_grad (which stay as the reference formulation for the tests) never reach HBM.
+// Similarities: one wave = 16 pixels x [21 own | 21 other | 6 pad] classes x 128 channels as 96 v_mfma_f32_16x16x4_f32 (exact
+// f32), identical arithmetic in both kernels, so the record's similarity is bit-identical to the one the loss uses.
+struct NceView { const float* F; const float* p_own; const float* p_oth; const int* y_own; const int* y_oth; const float* w_intra;
+                 const float* rkey; float* rec; float* dF; };
+struct NceArgs { NceView v[2]; int nviews, P; float coef_cross, coef_intra; float* sums; };
+
+// similarities of 16 pixels (rows grp16*16 ..) to the 42 prototypes held in pb; returns acc[t][r] = S[pixel 4g+r][class t*16+col]
+// already divided by the pixel's norm, and the lane's own row norm in `nr` (row = lane & 15)
+__device__ __forceinline__ void nce_sims16(const float* __restrict__ F, int P, int grp16, int col, int g, const f32x4 (&pb)[3][8],
+                                           f32x4 (&acc)[3], float& nr) {
+  const int row = grp16 * 16 + col;
+  const float* fr = F + (size_t)min(row, P - 1) * 128 + 4 * g;
+  f32x4 a[8];
+  float ss = 0.f;
+#pragma unroll
+  for (int b = 0; b < 8; ++b) { a[b] = *reinterpret_cast<const f32x4*>(fr + b * 16); ss += a[b][0] * a[b][0] + a[b][1] * a[b][1] + a[b][2] * a[b][2] + a[b][3] * a[b][3]; }
+  ss += __shfl_xor(ss, 16, 64); ss += __shfl_xor(ss, 32, 64);
+  nr = sqrtf(ss);
+  const float inv = 1.f / fmaxf(nr, 1e-12f);
+#pragma unroll
+  for (int t = 0; t < 3; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int b = 0; b < 8; ++b)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[b][e], pb[t][b][e], acc[t], 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float ir = __shfl(inv, 4 * g + r, 64);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) acc[t][r] *= ir;
+  }
+}
+
+__device__ __forceinline__ void nce_load_protos(const float* __restrict__ p_own, const float* __restrict__ p_oth, int col, int g, f32x4 (&pb)[3][8]) {
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int cc = t * 16 + col;
+    const float* src = cc < 21 ? p_own + cc * 128 : (cc < 42 && p_oth ? p_oth + (cc - 21) * 128 : nullptr);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) pb[t][b] = src ? *reinterpret_cast<const f32x4*>(src + b * 16 + 4 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+}
+
+__global__ __launch_bounds__(256) void nce_records_kernel(const NceArgs a) {
+  const int lane = threadIdx.x & 63, col = lane & 15, g = lane >> 4;
+  const int P = a.P, ngrp = (P + 15) >> 4;
+  {
+    for (int gid = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); gid < a.nviews * ngrp; gid += gridDim.x * 4) {   // both views share the grid
+      const NceView& v = a.v[gid >= ngrp ? 1 : 0];
+      const int grp = gid >= ngrp ? gid - ngrp : gid;
+      f32x4 pb[3][8];
+      nce_load_protos(v.p_own, nullptr, col, g, pb);
+      f32x4 acc[3]; float nr;
+      nce_sims16(v.F, P, grp, col, g, pb, acc, nr);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int p = grp * 16 + 4 * g + r;
+        if (p < P) {
+          const int c = v.y_own[p];                          // lane (col, g) holds classes col and 16 + col of pixel 4g + r
+          if (c == col) { v.rec[p] = __int_as_float(c); v.rec[P + p] = acc[0][r]; if (v.rkey) v.rec[2 * P + p] = v.rkey[p]; }
+          else if (c == 16 + col) { v.rec[p] = __int_as_float(c); v.rec[P + p] = acc[1][r]; if (v.rkey) v.rec[2 * P + p] = v.rkey[p]; }
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void nce_fused_kernel(const NceArgs a) {
+  __shared__ float slab[4][64][45];                          // per wave: [pixel][42 similarities -> 44 dS values | norm]
+  __shared__ float red[3][4];
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), col = lane & 15, g = lane >> 4;
+  const float itau = 10.f;                                   // 1 / 0.1
+  const int P = a.P, ngrp = (P + 63) >> 6;
+  float l_cross = 0.f, l_cross2 = 0.f, l_intra = 0.f;
+  {
+    for (int gid = blockIdx.x * 4 + wv; gid < a.nviews * ngrp; gid += gridDim.x * 4) {   // both views share the grid
+      const NceView& v = a.v[gid >= ngrp ? 1 : 0];
+      const int grp = gid >= ngrp ? gid - ngrp : gid;
+      // ---------------- similarities of 4 x 16 pixels -> the wave's slab
+      {
+        const float *po = v.p_own, *pt = v.p_oth;            // (opaque copies: keeps the compiler from hoisting the 96 prototype registers
+        asm volatile("" : "+s"(po), "+s"(pt));               //  of this phase and the 88 of phase B over the whole loop — they never overlap)
+        f32x4 pb[3][8];
+        nce_load_protos(po, pt, col, g, pb);
+#pragma unroll 1
+        for (int sub = 0; sub < 4; ++sub) {
+          f32x4 acc[3]; float nr;
+          nce_sims16(v.F, P, grp * 4 + sub, col, g, pb, acc, nr);
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+              const int cc = t * 16 + col;
+              if (cc < 42) slab[wv][sub * 16 + 4 * g + r][cc] = acc[t][r];
+            }
+          if (g == 0) slab[wv][sub * 16 + col][44] = nr;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      // ---------------- phase A, lane = pixel: the three InfoNCE terms and d(loss)/d(similarity)
+      {
+        const int p = grp * 64 + lane;
+        const bool ok = p < P;
+        const int pc = min(p, P - 1);
+        float so[21], st[21];
+#pragma unroll
+        for (int c = 0; c < 21; ++c) { so[c] = slab[wv][lane][c]; st[c] = slab[wv][lane][21 + c]; }
+        const int yo = v.y_own[pc], yt = v.y_oth[pc];
+        const float wi = ok ? v.w_intra[pc] : 0.f;
+        float eo[21], et[21], sum_o = 0.f, sum_t = 0.f, e_yo_t = 0.f, e_yt_o = 0.f, e_yo_o = 0.f;
+#pragma unroll
+        for (int c = 0; c < 21; ++c) {
+          eo[c] = expf(so[c] * itau); et[c] = expf(st[c] * itau);
+          sum_o += eo[c]; sum_t += et[c];
+          if (c == yo) { e_yo_t = et[c]; e_yo_o = eo[c]; }
+          if (c == yt) e_yt_o = eo[c];
+        }
+        float a2 = e_yo_o;                                   // semi-hard negatives: similarity ranks 3..12 (descending, lower index first on ties)
+        unsigned negmask = 0;
+#pragma unroll
+        for (int c = 0; c < 21; ++c) {
+          int rank = 0;
+#pragma unroll
+          for (int c2 = 0; c2 < 21; ++c2) rank += (so[c2] > so[c] || (so[c2] == so[c] && c2 < c)) ? 1 : 0;
+          if (rank >= 3 && rank <= 12) { negmask |= 1u << c; a2 += eo[c]; }
+        }
+        if (ok) {
+          l_cross += -logf(e_yo_t / sum_t) * a.coef_cross;   // cross-prototype: other view's prototypes, own label (:262)
+          l_cross2 += -logf(e_yt_o / sum_o) * a.coef_cross;  // cross-pseudo-label: own prototypes, other label (:272)
+          if (wi != 0.f) l_intra += -logf(e_yo_o / a2) * wi * a.coef_intra;
+        }
+        const float kc = ok ? a.coef_cross * itau : 0.f, ki = a.coef_intra * wi * itau;
+#pragma unroll
+        for (int c = 0; c < 21; ++c) {
+          float go = kc * (eo[c] / sum_o - (c == yt ? 1.f : 0.f));
+          if (wi != 0.f) go += ki * (((c == yo ? 1.f : 0.f) + ((negmask >> c) & 1u)) * eo[c] / a2 - (c == yo ? 1.f : 0.f));
+          slab[wv][lane][c] = go;
+          slab[wv][lane][21 + c] = kc * (et[c] / sum_t - (c == yo ? 1.f : 0.f));
+        }
+        slab[wv][lane][42] = 0.f; slab[wv][lane][43] = 0.f;
+      }
+      __builtin_amdgcn_wave_barrier();
+      // ---------------- phase B: d fn[ch][px] = sum_class [P_own|P_oth]^T[ch][class] * dS[class][px], then the F.normalize backward
+      {
+        const float *po = v.p_own, *pt = v.p_oth;
+        asm volatile("" : "+s"(po), "+s"(pt));
+        float pa[8][11];                                     // A operand: [P_own|P_oth]^T[ch = mt*16+col][class 4kk+g]
+#pragma unroll
+        for (int kk = 0; kk < 11; ++kk) {
+          const int cc = 4 * kk + g;
+          const float* src = cc < 21 ? po + cc * 128 : (cc < 42 ? pt + (cc - 21) * 128 : nullptr);
+#pragma unroll
+          for (int mt = 0; mt < 8; ++mt) pa[mt][kk] = src ? src[mt * 16 + col] : 0.f;
+        }
+#pragma unroll 1
+        for (int sub = 0; sub < 4; ++sub) {
+          const int p = grp * 64 + sub * 16 + col;           // B / C column = pixel
+          f32x4 acc[8];
+#pragma unroll
+          for (int mt = 0; mt < 8; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kk = 0; kk < 11; ++kk) {
+            const float bv = slab[wv][sub * 16 + col][4 * kk + g];
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[mt][kk], bv, acc[mt], 0, 0, 0);
+          }
+          const int pc = min(p, P - 1);
+          const float nr = slab[wv][sub * 16 + col][44];
+          const float inv_s = 1.f / fmaxf(nr, 1e-12f);
+          f32x4 f[8];
+          float dot = 0.f;
+#pragma unroll
+          for (int mt = 0; mt < 8; ++mt) {                   // (second touch of the wave's own 32 KB of features: cache-resident)
+            f[mt] = *reinterpret_cast<const f32x4*>(v.F + (size_t)pc * 128 + mt * 16 + 4 * g) * inv_s;
+            dot += acc[mt][0] * f[mt][0] + acc[mt][1] * f[mt][1] + acc[mt][2] * f[mt][2] + acc[mt][3] * f[mt][3];
+          }
+          dot += __shfl_xor(dot, 16, 64); dot += __shfl_xor(dot, 32, 64);
+          const float inv = nr > 1e-12f ? 1.f / nr : 0.f;    // below eps F.normalize divides by a constant: treat as dead
+          if (p < P) {
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt)
+              *reinterpret_cast<f32x4*>(v.dF + (size_t)p * 128 + mt * 16 + 4 * g) = (acc[mt] - f[mt] * dot) * inv;
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { l_cross += __shfl_xor(l_cross, o, 64); l_cross2 += __shfl_xor(l_cross2, o, 64); l_intra += __shfl_xor(l_intra, o, 64); }
+  if (lane == 0) { red[0][wv] = l_cross; red[1][wv] = l_cross2; red[2][wv] = l_intra; }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const float t = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+    if (t != 0.f) atomicAdd(&a.sums[threadIdx.x], t);
+  }
+}
+
 }  // namespace
 
 #define GRID1(total) dim3((unsigned)(((total) + 255) / 256)), dim3(256)
@@ -996,10 +1205,10 @@ extern "C" int wseg_nce_sims(const float* F, const float* p_own, const float* p_
   WSEG_LAUNCH_CHECK();
   return 0;
 }
-extern "C" int wseg_intra_weights(const int* y, const float* S_own, const float* rkey, const unsigned char* rand_flag, float* w, int P, void* stream) {
-  WSEG_CHECK(y && S_own && w && (rkey || rand_flag) && P > 0 && P <= 8192, "intra_weights: needs 0 < P <= 8192 (got %d)", P);
+extern "C" int wseg_intra_weights(const int* y, const float* S_own, int ld_s, const float* rkey, const unsigned char* rand_flag, float* w, int P, void* stream) {
+  WSEG_CHECK(y && S_own && w && (rkey || rand_flag) && P > 0 && P <= 8192 && (ld_s == 1 || ld_s == 21), "intra_weights: needs 0 < P <= 8192 (got %d), ld_s 1 or 21", P);
   int P2 = 1; while (P2 < P) P2 <<= 1;
-  hipLaunchKernelGGL(intra_weights_kernel, dim3(1), dim3(1024), (size_t)P2 * 8, ST, y, S_own, rkey, rand_flag, w, P);
+  hipLaunchKernelGGL(intra_weights_kernel, dim3(1), dim3(1024), (size_t)P2 * 8, ST, y, S_own, ld_s, rkey, rand_flag, w, P);
   WSEG_LAUNCH_CHECK();
   return 0;
 }
@@ -1022,6 +1231,35 @@ extern "C" int wseg_nce_loss_grad(const float* fn, const float* nrm, const float
   WSEG_CHECK(fn && nrm && S_own && S_oth && y_own && y_oth && w_intra && p_own && p_oth && dF && sums && P > 0, "nce_loss_grad: bad arguments");
   hipLaunchKernelGGL(nce_loss_grad_kernel, dim3(std::min(2048, (P + 255) / 256)), dim3(256), 0, ST, fn, nrm, S_own, S_oth, y_own, y_oth, w_intra, p_own, p_oth,
                      dF, sums, P, coef_cross, coef_intra);
+  WSEG_LAUNCH_CHECK();
+  return 0;
+}
+
+static int nce_args(const wseg_nce_view* views, int nviews, int P, NceArgs& a, bool need_grad) {
+  WSEG_CHECK(views && (nviews == 1 || nviews == 2) && P > 0, "nce: needs 1 or 2 views and P > 0");
+  a.nviews = nviews; a.P = P;
+  for (int i = 0; i < nviews; ++i) {
+    const wseg_nce_view& w = views[i];
+    WSEG_CHECK(w.F && w.p_own && w.y_own, "nce: view %d: F, p_own, y_own are required", i);
+    if (need_grad) WSEG_CHECK(w.p_oth && w.y_oth && w.w_intra && w.dF, "nce_fused: view %d: p_oth, y_oth, w_intra, dF are required", i);
+    else WSEG_CHECK(w.rec, "nce_records: view %d: rec is required", i);
+    a.v[i] = NceView{w.F, w.p_own, w.p_oth, w.y_own, w.y_oth, w.w_intra, w.rkey, w.rec, w.dF};
+  }
+  return 0;
+}
+extern "C" int wseg_nce_records(const wseg_nce_view* views, int nviews, int P, void* stream) {
+  NceArgs a{};
+  if (int rc = nce_args(views, nviews, P, a, false)) return rc;
+  hipLaunchKernelGGL(nce_records_kernel, dim3(std::min(2048, (nviews * ((P + 15) / 16) + 3) / 4)), dim3(256), 0, ST, a);
+  WSEG_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int wseg_nce_fused(const wseg_nce_view* views, int nviews, int P, float coef_cross, float coef_intra, float* sums, void* stream) {
+  NceArgs a{};
+  WSEG_CHECK(sums, "nce_fused: sums is null");
+  if (int rc = nce_args(views, nviews, P, a, true)) return rc;
+  a.coef_cross = coef_cross; a.coef_intra = coef_intra; a.sums = sums;
+  hipLaunchKernelGGL(nce_fused_kernel, dim3(std::min(2048, (nviews * ((P + 63) / 64) + 3) / 4)), dim3(256), 0, ST, a);
   WSEG_LAUNCH_CHECK();
   return 0;
 }

@@ -4,8 +4,8 @@ needs torchvision and the removed PIL.Image.CUBIC).  Not part of the accelerated
 
 List files: one line per image, `/JPEGImages/<name>.jpg [/SegmentationClassAug/<name>.png]`; the image
 name is characters [-15:-4] of the first field (voc12/data.py:49-55).  Labels: a pickled dict
-name -> float32[20] (`cls_labels.npy`, voc12/data.py:40-44) — loaded with allow_pickle only when the
-file is one this repo's tools wrote; a plain .npz (names, labels) is accepted too.
+name -> float32[20] (`cls_labels.npy`, voc12/data.py:40-44) — read by a restricted unpickler that admits numeric numpy
+containers only (wseg_amd/safe_npy.py: the file is untrusted input); a plain .npz (names, labels) is accepted too.
 """
 import os
 import random
@@ -16,12 +16,24 @@ import PIL.ImageEnhance
 import torch
 from torch.utils.data import Dataset
 
+from .safe_npy import load_pickled_npy
+
 IMG_FOLDER_NAME = "JPEGImages"
 BICUBIC = PIL.Image.Resampling.BICUBIC
 
 
+def img_name_of(line):
+    """Image name of one list line: `voc12/*.txt` lines are `/JPEGImages/<name>.jpg [/SegmentationClassAug/<name>.png]`
+    (voc12/data.py:49-55 takes characters [-15:-4] of the first field); the devkit's `ImageSets/Segmentation/*.txt` lists that
+    eval.py:112 reads hold the bare name."""
+    first = line.strip().split(' ')[0]
+    if '/' in first or first.lower().endswith(('.jpg', '.png')):
+        return os.path.splitext(os.path.basename(first))[0]
+    return first
+
+
 def load_img_name_list(dataset_path):
-    return [line.split(' ')[0][-15:-4] for line in open(dataset_path).read().splitlines() if line.strip()]
+    return [img_name_of(line) for line in open(dataset_path).read().splitlines() if line.strip()]
 
 
 def get_img_path(img_name, voc12_root):
@@ -33,7 +45,7 @@ def load_labels(path, names):
         z = np.load(path)
         table = dict(zip([str(n) for n in z["names"]], z["labels"].astype(np.float32)))
     else:
-        table = np.load(path, allow_pickle=True).item()
+        table = load_pickled_npy(path)
     return [np.asarray(table[n], np.float32) for n in names]
 
 

@@ -10,6 +10,8 @@ The whole network is one torch.autograd.Function: its backward runs the hand-wri
 wgrad / PCM-backward kernels and accumulates straight into the flat gradient buffer.
 """
 import os
+import threading
+import weakref
 
 import torch
 
@@ -27,8 +29,16 @@ def _out_size(h, k, s, d):
 
 
 class Engine:
-    def __init__(self, net):
-        self.__dict__["net"] = net          # plain attribute: not a sub-module
+    """One per Net INSTANCE (a replica made by nn.parallel.replicate gets its own, see Net._replicate_for_data_parallel).
+    Re-entrancy (contrast_infer.py:69-73 calls one module from 8 threads): everything that mutates engine state — the flat
+    buffers, the packs, the parameters' `.data` — happens under `self.lock`; a forward pass itself only reads them and
+    allocates its own activations."""
+
+    def __init__(self, net, parent=None):
+        self._net_ref = weakref.ref(net)    # (no reference cycle; the Net owns the Engine)
+        self.parent = parent                # replica: the engine of the module it was replicated from
+        self.lock = threading.RLock()
+        self.delegate = None                # set by ensure_flat on a replica that aliases its parent's flat buffer
         self.flat_w = None
         self.flat_g = None
         self.packs = None
@@ -39,6 +49,15 @@ class Engine:
         self.flat_wb = None
         self.flat_wb_version = None
         self.block_done_hook = None         # called with the block name when all of its weight gradients are enqueued
+        self.capture_ctx = False            # tests: keep the saved forward context of the last training pass in `last_ctx`
+        self.last_ctx = None
+
+    @property
+    def net(self):
+        net = self._net_ref()
+        if net is None:
+            raise RuntimeError("wseg_amd.Engine outlived its Net")
+        return net
 
     # ------------------------------------------------------------------ parameters
     def conv_param(self, name):
@@ -66,10 +85,37 @@ class Engine:
             self._order = names
         return self._order
 
+    def __deepcopy__(self, memo):
+        return None                         # a copied Net builds its own engine on first use (Net._engine)
+
+    def __reduce__(self):
+        return (type(None), ())             # pickling a whole Net: the engine is derived state
+
     def ensure_flat(self, device):
-        """(Re)build the flat weight / gradient buffers when the parameters moved."""
+        """(Re)build the flat weight / gradient buffers when the parameters moved.  Serialised: eight inference threads may
+        enter a fresh module at once (contrast_infer.py:69-73)."""
+        with self.lock:
+            self._ensure_flat(device)
+
+    def active(self, device):
+        """The engine whose buffers serve this module on `device`: itself, or the original's for an aliasing replica."""
+        self.ensure_flat(device)
+        return self.delegate if self.delegate is not None else self
+
+    def _ensure_flat(self, device):
         names = self.trainable_order()
         first = self.conv_param(names[0])
+        self.delegate = None
+        par = self.parent
+        if par is not None:
+            # a replica on the original's device holds ALIASES of the original's parameters (nn.parallel.replicate hands device 0
+            # the source tensors): when those already live in the original engine's flat buffer, its buffers and packs serve
+            # this replica as they are; anything else (other device, original not flattened yet) gets buffers of its own below
+            with par.lock:
+                if (par.flat_w is not None and first.device == par.flat_w.device == device
+                        and first.data_ptr() == par.flat_w.data_ptr()):
+                    self.delegate = par
+                    return
         if (self.flat_w is not None and self.flat_w.device == first.device
                 and first.data_ptr() == self.flat_w.data_ptr() and first.device == device):
             return
@@ -140,6 +186,10 @@ class Engine:
         return scale.contiguous(), shift.contiguous()
 
     def ensure_packs(self, device, dt, defer_wt=False):
+        with self.lock:
+            return self._ensure_packs(device, dt, defer_wt)
+
+    def _ensure_packs(self, device, dt, defer_wt=False):
         """Packed (cast / transposed) weights + folded BatchNorms.  Frozen pieces (every BN, conv1a, b2*) are
         cached on their own key so a training step only re-packs the 40 trainable tensors.
         defer_wt: the transposed (dgrad) packs are only needed by the backward pass — the fused training step lets
@@ -306,6 +356,8 @@ class Engine:
             raise RuntimeError("wseg_amd.Net runs only on an MI355X (HIP) device; there is no CPU fallback")
         x = x.contiguous().float()
         self.ensure_flat(x.device)
+        if self.delegate is not None:                         # replica whose parameters alias the original's flat buffer
+            return self.delegate.forward(x, lowres)
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.net.parameters())
         if need_grad:
             anchor = self.flat_w.new_zeros((), requires_grad=True)
@@ -460,6 +512,8 @@ class Engine:
                 L.resize_planar_fwd(rvd, cam_rv, N * 21, h, w, H, W, True)
                 outs.append((cam, cam_rv, f_proj.float() if dt == L.BF16 else f_proj, rvd))
             vw.update(rvd=rvd.clone() if save else None, den=den)
+        if save and self.capture_ctx:
+            self.last_ctx = S
         if save:
             S.update(fea=fea, head=head, G=G, feat=feat, Fm=Fm, Fh=Fh, Fb=Fb, Gb=Gb, nrm=nrm, conv4=conv4, conv5=conv5,
                      views=views, hdims=dims, M=M)
@@ -516,6 +570,14 @@ class Engine:
                     wstream.wait_event(main.record_event())
                     with torch.cuda.stream(wstream):
                         L.conv_wgrad(x, dy, self.flat_g[off:off + n], **args)
+
+        def block_done(nm):
+            """All weight gradients of block `nm` are enqueued: the data-parallel trainer may start reducing its bucket.  With a
+            separate wgrad stream the collective (issued behind `main`) must first wait for the kernels on that stream."""
+            if self.block_done_hook is not None:
+                if wstream is not None:
+                    main.wait_event(wstream.record_event())
+                self.block_done_hook(nm)
 
         def dgrad(dy, wname, out, conv_cin, conv_cout, k, stride, dil, din, dout, **kw):
             # in = dY over the conv's OUTPUT dims (dout), out = dX over its INPUT dims (din)
@@ -610,8 +672,7 @@ class Engine:
                 if not same:
                     wgrad(name + ".conv_branch1", sv["t"], D, cin, cout, 1, stride, 1, din, dout)
                 if first_trainable:
-                    if self.block_done_hook is not None:
-                        self.block_done_hook(name)
+                    block_done(name)
                     break
                 Din = E(Mi, cin)
                 if same:
@@ -625,8 +686,7 @@ class Engine:
                     dgrad(D, name + ".conv_branch1", tmp, cin, cout, 1, stride, 1, din, dout)
                     dgrad(du, name + ".conv_branch2a", Din, cin, mid, 3, stride, fd, din, dout, epi=1, scale=sa, mask=sv["t"], r_pre=tmp)
                 D = Din
-                if self.block_done_hook is not None:
-                    self.block_done_hook(name)
+                block_done(name)
             else:
                 c4, c2 = cout // 4, cout // 2
                 s1, _ = P["bn"][name + ".bn_branch2b1"]
@@ -651,8 +711,7 @@ class Engine:
                     dgrad(D, name + ".conv_branch1", tmp, cin, cout, 1, stride, 1, din, dout)
                     dgrad(du1, name + ".conv_branch2a", Din, cin, c4, 1, stride, 1, din, dout, epi=1, scale=sa, mask=sv["t"], r_pre=tmp)
                 D = Din
-                if self.block_done_hook is not None:
-                    self.block_done_hook(name)
+                block_done(name)
         if wstream is not None:
             main.wait_stream(wstream)
             keep.clear()

@@ -14,6 +14,9 @@ import os
 import numpy as np
 import PIL.Image
 
+from .data import load_img_name_list
+from .safe_npy import load_pickled_npy
+
 CATEGORIES = ['background', 'aeroplane', 'bicycle', 'bird', 'boat', 'bottle', 'bus', 'car', 'cat', 'chair', 'cow',
               'diningtable', 'dog', 'horse', 'motorbike', 'person', 'pottedplant', 'sheep', 'sofa', 'train', 'tvmonitor']
 
@@ -21,7 +24,7 @@ CATEGORIES = ['background', 'aeroplane', 'bicycle', 'bird', 'boat', 'bottle', 'b
 def load_prediction(folder, name, input_type, threshold, num_cls=21):
     if input_type == 'png':
         return np.array(PIL.Image.open(os.path.join(folder, name + '.png')))
-    d = np.load(os.path.join(folder, name + '.npy'), allow_pickle=True).item()       # file written by contrast_infer
+    d = load_pickled_npy(os.path.join(folder, name + '.npy'))       # dict class -> float32[H,W] (restricted unpickler)
     h, w = list(d.values())[0].shape
     tensor = np.zeros((num_cls, h, w), np.float32)
     for key, v in d.items():
@@ -61,7 +64,7 @@ def main(argv=None):
     ap.add_argument("--t", default=None, type=float)
     ap.add_argument("--curve", action="store_true")
     a = ap.parse_args(argv)
-    names = [line.split(' ')[0][-15:-4] for line in open(a.list).read().splitlines() if line.strip()]
+    names = load_img_name_list(a.list)              # both list formats: voc12/*.txt path lines and the devkit's bare names
     if not a.curve:
         res = do_eval(names, a.predict_dir, a.gt_dir, a.type, a.t if a.t is not None else 1.0)
         print('mIoU: %.3f' % res['mIoU'])

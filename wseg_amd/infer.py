@@ -43,8 +43,7 @@ def infer_image(model, img_list, label20, orig_size, alpha=0.26):
         if b is None:
             outs = [model(batches[a][1])]
         else:
-            eng.ensure_flat(dev)
-            outs, _ = eng.run_forward([batches[a][1].float(), batches[b][1].float()], save=False)
+            outs, _ = eng.active(dev).run_forward([batches[a][1].float(), batches[b][1].float()], save=False)
         for k, out in zip((a, b), outs):
             for j in range(out[1].shape[0]):
                 maps[batches[k][0] + j] = out[1][j, 1:].contiguous()      # planes 1..20 (contrast_infer.py:62 `cam[:, 1:, :, :]`, `[0]`)

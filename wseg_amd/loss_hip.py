@@ -234,19 +234,16 @@ def step(model, img1, img2, label20, bg_threshold=0.20, rng=None, rng_parity=Fal
     cst = side[1]
     cst.wait_stream(main)
     with torch.cuda.stream(cst):
-        for v, o in ((v1, v2), (v2, v1)):
-            v.fn, v.nrm = _f32(P, 128, dev=dev), _f32(P, dev=dev)
-            v.S_own, v.S_oth = _f32(P, 21, dev=dev), _f32(P, 21, dev=dev)
-            L.nce_sims(v.F, v.protos, o.protos, v.fn, v.nrm, v.S_own, v.S_oth, P)
-        if global_intra:
-            # Hard-pixel sampling over the GLOBAL batch (the reference samples on the gathered batch): one
-            # all-gather of {label, own-class similarity, random key} per pixel (96 KB per rank for both views); every rank
-            # then finds the same global per-class order statistics and keeps the weights of its own pixels, scaled by
-            # `world` because the gradient all-reduce averages.
-            rec = _f32(2, 3, P, dev=dev)
-            for vi, v in enumerate(views):
-                L.intra_pack(v.y, v.S_own, _random_keys(P, rank, vi, dev), rec[vi], P)
-            grec = rec
+        # ONE launch for both views: per-pixel records {label, similarity to the pixel's own-class prototype, random key} straight from
+        # the raw features (csrc/loss.hip nce_records): the inputs of the hard-pixel sampling.  Over the GLOBAL batch under data
+        # parallelism (the reference samples on the gathered batch): the records (96 KB per rank for both views) are
+        # all-gathered, every rank finds the same global per-class order statistics and keeps the weights of its own pixels, scaled
+        # by `world` because the gradient all-reduce averages.
+        rec = _f32(2, 3, P, dev=dev)
+        for vi, v in enumerate(views):
+            v.rkey = _random_keys(P, rank, vi, dev) if global_intra else None
+        L.nce_records([dict(F=v.F, p_own=v.protos, y_own=v.y, rkey=v.rkey, rec=rec[vi]) for vi, v in enumerate(views)], P)
+        grec = rec
     # ---- ER + ECR on the 128x128 maps (both directions of the ECR top-k in ONE 2N-row selection)
     npix = 128 * 128
     er_coef = 1.0 / (N * 20 * npix)
@@ -267,9 +264,9 @@ def step(model, img1, img2, label20, bg_threshold=0.20, rng=None, rng_parity=Fal
         grec = _f32(world, 2, 3, P, dev=dev)
         dist.all_gather_into_tensor(grec.view(world * 6, P), rec.view(6, P))
     elif rng_parity and not global_intra:
-        for v in views:                                    # view 1 fully before view 2 (RNG order of the reference)
+        for vi, v in enumerate(views):                     # view 1 fully before view 2 (RNG order of the reference)
             v.w_intra = _f32(P, dev=dev)
-            L.intra_weights(v.y, v.S_own, None, _rand_flags(v.y, rng, P), v.w_intra, P)
+            L.intra_weights(v.y, rec[vi, 1], None, _rand_flags(v.y, rng, P), v.w_intra, P, ld_s=1)
     # per view, again on its own stream: hard-pixel weights (a single-workgroup kernel) and the map backward
     fork2 = main.record_event()
     for vi, (v, st) in enumerate(zip(views, side)):
@@ -280,14 +277,15 @@ def step(model, img1, img2, label20, bg_threshold=0.20, rng=None, rng_parity=Fal
                 L.intra_weights_global(grec.view(-1)[vi * 3 * P:], v.w_intra, P, world, rank, float(world), 6 * P)
             elif not rng_parity:
                 v.w_intra = _f32(P, dev=dev)
-                L.intra_weights(v.y, v.S_own, torch.rand(P, device=dev), None, v.w_intra, P)
+                L.intra_weights(v.y, rec[vi, 1], torch.rand(P, device=dev), None, v.w_intra, P, ld_s=1)
             _maps_backward(v, label20, N)
     for st in side:
         main.wait_stream(st)
-    for v, o in ((v1, v2), (v2, v1)):
+    # similarities, the three InfoNCE terms and dF of BOTH views in one launch (csrc/loss.hip nce_fused): features read once, only dF written
+    for v in views:
         v.dF = _f32(P, 128, dev=dev)
-        L.nce_loss_grad(v.fn, v.nrm, v.S_own, v.S_oth, v.y, o.y, v.w_intra, v.protos, o.protos, v.dF, acc[4:7], P,
-                        0.1 / (2 * P), 0.05)
+    L.nce_fused([dict(F=v.F, p_own=v.protos, p_oth=o.protos, y_own=v.y, y_oth=o.y, w_intra=v.w_intra, dF=v.dF) for v, o in ((v1, v2), (v2, v1))],
+                P, 0.1 / (2 * P), 0.05, acc[4:7])
     # ---- into the network: one batched backward over both views
     d_head = torch.empty_like(ctx["head"])
     for v in views:

@@ -82,7 +82,16 @@ class Net(nn.Module):
         self.normalize = Normalize()
         self.precision = precision or os.environ.get("WSEG_PRECISION", "bf16")
         assert self.precision in ("bf16", "fp32")
-        self._engine = engine.Engine(self)
+
+    @property
+    def _engine(self):
+        """The engine of THIS module instance.  A shallow copy of the module (`nn.parallel.replicate`, contrast_infer.py:47)
+        arrives with the original's engine in its __dict__: it gets one of its own, whose parent is the original's."""
+        eng = self.__dict__.get("_wseg_engine")
+        if eng is None or eng._net_ref() is not self:
+            eng = engine.Engine(self, parent=eng)
+            self.__dict__["_wseg_engine"] = eng
+        return eng
 
     # ---- reference API -------------------------------------------------------------------
     def forward(self, x):

@@ -12,7 +12,6 @@ import torch
 import torch.distributed as dist
 
 from . import _lib as L
-from . import loss_aten
 
 
 def dist_state():
@@ -35,18 +34,16 @@ def second_view(img1, size=128):
 
 
 class Trainer:
-    def __init__(self, model, optimizer, bg_threshold=0.20, rng=None, rng_parity=False, loss_impl="hip",
-                 bg_topk_idx=None):
+    def __init__(self, model, optimizer, bg_threshold=0.20, rng=None, rng_parity=False, bg_topk_idx=None):
         self.model = model
         self.optimizer = optimizer
         self.bg_threshold = bg_threshold
         self.rng = rng if rng is not None else _random.Random()
         self.rng_parity = rng_parity
-        self.loss_impl = loss_impl
         self.bg_topk_idx = bg_topk_idx
         self.world, self.distributed = dist_state()
         self._pending = []
-        if self.distributed and loss_impl == "hip" and os.environ.get("WSEG_BUCKETS", "1") != "0":   # (one joint backward)
+        if self.distributed and os.environ.get("WSEG_BUCKETS", "1") != "0":   # (one joint backward)
             # Gradient all-reduce overlapped with backward: the flat gradient buffer completes back to front, so each
             # bucket (b7 + heads, b5..b6, b4*, b3*: 154 / 143 / 109 / 13 MB) is reduced as soon as its last weight
             # gradient is enqueued — RCCL runs on its own stream behind those kernels while dgrad/wgrad continue.
@@ -64,21 +61,17 @@ class Trainer:
     def step(self, img1, label20):
         if not img1.is_cuda:
             raise RuntimeError("Trainer.step needs GPU tensors (no CPU fallback)")
-        model, opt = self.model, self.optimizer
+        from . import loss_hip
         img1 = img1.contiguous().float()
         img2 = second_view(img1)
-        fused = self.loss_impl != "aten"
-        opt.zero_grad(flat=not fused)                       # (the fused step clears the flat gradient buffer itself, off the critical path)
-        if self.loss_impl == "aten":
-            out1 = model(img1)
-            out2 = model(img2)
-            losses = loss_aten.step_loss(out1, out2, label20, self.bg_threshold, self.rng, self.rng_parity,
-                                         self.bg_topk_idx)
-            losses["loss"].backward()
-        else:
-            from . import loss_hip
-            losses = loss_hip.step(model, img1, img2, label20, self.bg_threshold, self.rng, self.rng_parity,
-                                   self.bg_topk_idx, zero_grads=True)
+        self.optimizer.zero_grad(flat=False)                # (the fused step clears the flat gradient buffer itself, off the critical path)
+        losses = loss_hip.step(self.model, img1, img2, label20, self.bg_threshold, self.rng, self.rng_parity,
+                               self.bg_topk_idx, zero_grads=True)
+        return self.finish_step(losses)
+
+    def finish_step(self, losses):
+        """Gradient all-reduce (data parallel) + optimizer step; returns the logged scalars detached."""
+        model, opt = self.model, self.optimizer
         if self.distributed:
             if self._pending:                               # bucketed all-reduces launched during backward
                 for work in self._pending:
