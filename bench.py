@@ -117,7 +117,8 @@ def main():
     ap.add_argument("--cpu-baseline-n", default="2,16", help="batch sizes of the CPU-oracle leg (BASELINE.md §3: N=2 and N=16)")
     ap.add_argument("--parity-steps", type=int, default=2,
                     help="timed steps of the parity (f32-exact) mode reported as `parity_mode` beside the bf16 line (0: skip)")
-    ap.add_argument("--parity-precision", default=os.environ.get("WSEG_PARITY_PRECISION", "fp32"), choices=["fp32", "bf16x3"])
+    ap.add_argument("--parity-precision", default=os.environ.get("WSEG_PARITY_PRECISION", "fp32,bf16x3"),
+                    help="comma list of the parity-grade modes to time: fp32 (exact-f32 MFMA), bf16x3 (f32 storage, split-bf16 products)")
     ap.add_argument("--event-stride", type=int, default=5, help="bracket every k-th conv launch with HIP events (rotating)")
     ap.add_argument("--seed", type=int, default=0, help="base seed: rank r draws its images / labels / dropout masks / keys from seed + r")
     ap.add_argument("--lr", type=float, default=1e-5,
@@ -226,16 +227,18 @@ def main():
     if rank == 0 and world == 1 and a.parity_steps > 0 and a.precision == "bf16":
         del trainer, model
         torch.cuda.empty_cache()
-        pmodel, ptrainer = build_trainer(a.parity_precision, a.lr, dev, a.seed + rank)
-        pdt, plosses = timed_steps(ptrainer, img, lab, a.parity_steps, 1, barrier)
-        pms = pdt / a.parity_steps * 1e3
-        ppeak = PEAKS[a.parity_precision]
-        line["parity_mode"] = {"precision": a.parity_precision, "ms_per_step": round(pms, 2), "value": round(a.batch * a.parity_steps / pdt, 2),
-                               "unit": "images/sec", "steps": a.parity_steps, "warmup": 1, "peak_tflops": round(ppeak, 1),
-                               "whole_step_frac": round(conv_flops_model() * a.batch / (pms * 1e-3) / 1e12 / ppeak, 4),
-                               "loss": float(plosses["loss"])}
-        del ptrainer, pmodel
-        torch.cuda.empty_cache()
+        line["parity_mode"] = []
+        for pprec in a.parity_precision.split(","):
+            pmodel, ptrainer = build_trainer(pprec, a.lr, dev, a.seed + rank)
+            pdt, plosses = timed_steps(ptrainer, img, lab, a.parity_steps, 1, barrier)
+            pms = pdt / a.parity_steps * 1e3
+            ppeak = PEAKS[pprec]
+            line["parity_mode"].append({"precision": pprec, "ms_per_step": round(pms, 2), "value": round(a.batch * a.parity_steps / pdt, 2),
+                                        "unit": "images/sec", "steps": a.parity_steps, "warmup": 1, "peak_tflops": round(ppeak, 1),
+                                        "whole_step_frac": round(conv_flops_model() * a.batch / (pms * 1e-3) / 1e12 / ppeak, 4),
+                                        "loss": float(plosses["loss"])})
+            del ptrainer, pmodel
+            torch.cuda.empty_cache()
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(tuple(int(x) for x in a.cpu_baseline_n.split(",")))

@@ -12,7 +12,10 @@
  *     (contrast_infer.py:69-73 calls forward from 8 threads);
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it;
  *   - activations are NHWC ("pixel rows"): element (n,y,x,c) at ((n*H+y)*W+x)*ld + c;
- *   - dtype: 0 = f32 (exact-f32 MFMA, parity mode), 1 = bf16 (bf16 MFMA, f32 accumulate);
+ *   - dtype: 0 = f32 (exact-f32 MFMA, parity mode), 1 = bf16 (bf16 MFMA, f32 accumulate), 2 = f32 storage with split-bf16 products
+ *     (conv / wgrad only: every f32 operand x = hi + lo with hi = bf16(x), lo = bf16(x - hi); the product is hi.hi + lo.hi + hi.lo on
+ *     the bf16 MFMA with f32 accumulate — 16-17 operand bits at 3 bf16 MFMAs per product instead of the 8x slower f32 MFMA; activations
+ *     are split in the kernel, weights arrive pre-split: wseg_pack_x3);
  *   - return 0 on success, negative on error; wseg_last_error() gives the thread-local message.
  */
 #ifndef WSEG_HIP_H
@@ -25,6 +28,7 @@ extern "C" {
 
 #define WSEG_F32 0
 #define WSEG_BF16 1
+#define WSEG_F32X3 2
 
 int wseg_version(void);
 /* sizeof(wseg_conv_desc) / sizeof(wseg_wgrad_desc) as this build sees them: a binding checks its mirror of the descriptors against
@@ -164,6 +168,11 @@ int wseg_l2norm_backward(const void* F, int ldf, const float* dFh, const float* 
 int wseg_pcm_forward(const float* Fh, const float* G, float* cam_rv, float* den, int N, int hw, void* stream);
 int wseg_pcm_backward(const float* Fh, const float* G, const float* d_cam_rv, const float* cam_rv, const float* den,
                       float* DN, float* dFh, int N, int hw, void* stream);
+/* split-bf16 weight pack for dtype WSEG_F32X3: f32 [.. x K] (K % 32 == 0 per row, numel % 32 == 0) -> per 32-element group
+ * [32 hi bf16 | 32 lo bf16] in the same 128 bytes; `src` = a forward pack [OC][T][IC] or a transposed pack [IC][T][OC] in f32. */
+int wseg_pack_x3(const float* src, void* dst, long numel, void* stream);
+/* f32 [total] -> bf16 planes hi, lo with in = hi + lo to 16-17 bits (16-B aligned, contiguous) */
+int wseg_split_bf16(const float* in, void* hi, void* lo, long total, void* stream);
 /* bf16-MFMA variants for the bf16 throughput mode (Fb/Gb/DNb = bf16 copies made with wseg_to_bf16) */
 int wseg_to_bf16(const float* in, void* out, long total, void* stream);
 int wseg_pcm_forward_bf16(const void* Fb, const void* Gb, float* cam_rv, float* den, int N, int hw, void* stream);

@@ -11,6 +11,7 @@ from oracle import infer as oinfer, loss as oloss, net as onet
 from wseg_amd import synth
 
 TERMS = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+ROUND_RESIDUAL = len(sys.argv) > 2 and sys.argv[2] == "planes"      # also keep the residual stream (block outputs) as hi + lo planes (16-17 bits)
 
 
 def split(x, n):
@@ -41,6 +42,14 @@ class SplitF:
 G = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 sd = synth.procedural_state_dict(0)
 onet.F = SplitF()
+if ROUND_RESIDUAL:
+    _res, _bot = onet.res_block, onet.bot_block
+
+    def _r(x):
+        hi = x.bfloat16().float()
+        return hi + (x - hi).bfloat16().float()
+    onet.res_block = lambda *a, **k: (lambda o: (_r(o[0]), o[1]))(_res(*a, **k))
+    onet.bot_block = lambda *a, **k: (lambda o: (_r(o[0]), o[1]))(_bot(*a, **k))
 for name in ("infer_1img", "infer_125x94", "infer_188x250"):
     g = np.load(os.path.join(G, name + ".npz"))
     H, W = int(g["H"]), int(g["W"])
@@ -50,7 +59,7 @@ for name in ("infer_1img", "infer_125x94", "infer_188x250"):
         im = synth.synthetic_images(1, (int(np.round(H * s)), int(np.round(W * s))), seed0 + si)
         imgs += [im, torch.flip(im, dims=[3])]
     norm, pred, _ = oinfer.infer_one(imgs, torch.from_numpy(g["label"]), sd, (H, W), 0.26)
-    print(f"{TERMS} products: {name}: arg-max mismatches {int((pred != g['pred']).sum())} of {pred.size}", flush=True)
+    print(f"{TERMS} products{' + planes residual' if ROUND_RESIDUAL else ''}: {name}: arg-max mismatches {int((pred != g['pred']).sum())} of {pred.size}", flush=True)
 g = np.load(os.path.join(G, "step_S128_N3.npz"))
 n, size, seed, py_seed = int(g["n"]), int(g["size"]), int(g["seed"]), int(g["py_seed"])
 with torch.no_grad():

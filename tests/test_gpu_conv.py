@@ -32,12 +32,15 @@ CASES = [
 
 
 @pytest.mark.parametrize("bm", [64, 128])
-@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("dt", ["f32", "bf16", "x3"])
 @pytest.mark.parametrize("case", CASES)
 def test_conv_fwd_dgrad_wgrad(case, dt, bm):
+    """dt x3 = WSEG_F32X3: f32 tensors, products as split-bf16 (hi.hi + lo.hi + hi.lo on the bf16 MFMA, f32 accumulate); the
+    activations are split in the kernels, the weight packs arrive pre-split (wseg_pack_x3)."""
     from wseg_amd import _lib as L
     N, H, W, IC, OC, k, s, d = case
-    tdt = torch.float32 if dt == "f32" else torch.bfloat16
+    tdt = torch.bfloat16 if dt == "bf16" else torch.float32
+    cdt = L.F32X3 if dt == "x3" else None
     pad = d * (k // 2)
     OH = (H + 2 * pad - d * (k - 1) - 1) // s + 1
     OW = (W + 2 * pad - d * (k - 1) - 1) // s + 1
@@ -48,7 +51,7 @@ def test_conv_fwd_dgrad_wgrad(case, dt, bm):
     w.requires_grad_(True)
     y = F.conv2d(x, w, None, s, pad, d)
     y.backward(dy)
-    tol = dict(rtol=2e-5, atol=2e-5) if dt == "f32" else dict(rtol=2e-2, atol=2e-2)
+    tol = {"f32": dict(rtol=2e-5, atol=2e-5), "x3": dict(rtol=1e-4, atol=1e-4), "bf16": dict(rtol=2e-2, atol=2e-2)}[dt]
 
     dev = "cuda"
     xg = _nhwc(x.detach()).to(dev, tdt)
@@ -57,27 +60,33 @@ def test_conv_fwd_dgrad_wgrad(case, dt, bm):
     wf = torch.empty(OC, k * k, IC, device=dev, dtype=tdt)
     wt = torch.empty(IC, k * k, OC, device=dev, dtype=tdt)
     L.pack_weights(wm, wf, wt, OC, k * k, IC, OC, IC, L.dtype_code(wf))
+    if dt == "x3":
+        wf32, wt32 = wf, wt
+        wf, wt = torch.empty_like(wf32), torch.empty_like(wt32)
+        L.pack_x3(wf32, wf)
+        if (OC * 4) % 128 == 0:
+            L.pack_x3(wt32, wt)
     # forward
     yg = torch.empty(N, OH, OW, OC, device=dev, dtype=tdt)
-    L.conv_igemm(xg, wf, yg, N=N, IH=H, IW=W, IC=IC, OH=OH, OW=OW, OC=OC, KH=k, KW=k, stride=s, dil=d, pad=pad, bm_hint=bm)
+    L.conv_igemm(xg, wf, yg, N=N, IH=H, IW=W, IC=IC, OH=OH, OW=OW, OC=OC, KH=k, KW=k, stride=s, dil=d, pad=pad, bm_hint=bm, dtype=cdt)
     np.testing.assert_allclose(yg.float().cpu().numpy(), _nhwc(y.detach()).numpy(), **tol)
     # data gradient (needs OC % (128B/es) == 0 as the reduction dim)
-    es = 4 if dt == "f32" else 2
+    es = 2 if dt == "bf16" else 4
     dyg = _nhwc(dy).to(dev, tdt)
     if (OC * es) % 128 == 0:
         dxg = torch.empty(N, H, W, IC, device=dev, dtype=tdt)
-        L.conv_igemm(dyg, wt, dxg, N=N, IH=OH, IW=OW, IC=OC, OH=H, OW=W, OC=IC, KH=k, KW=k, stride=s, dil=d, pad=pad, mode=1, bm_hint=bm)
+        L.conv_igemm(dyg, wt, dxg, N=N, IH=OH, IW=OW, IC=OC, OH=H, OW=W, OC=IC, KH=k, KW=k, stride=s, dil=d, pad=pad, mode=1, bm_hint=bm, dtype=cdt)
         np.testing.assert_allclose(dxg.float().cpu().numpy(), _nhwc(x.grad).numpy(), **tol)
     # weight gradient (f32, accumulating)
     dwg = torch.zeros(OC, k * k, IC, device=dev, dtype=torch.float32)
     L.conv_wgrad(xg, dyg, dwg, N=N, IH=H, IW=W, IC=IC, OH=OH, OW=OW, OC=OC, KH=k, KW=k, stride=s, dil=d, pad=pad,
-                 tile_hint=256 if bm == 128 else 128)
+                 tile_hint=256 if bm == 128 else 128, dtype=cdt)
     ref = w.grad.permute(0, 2, 3, 1).reshape(OC, k * k, IC).numpy()
     scale = np.abs(ref).max()
-    wtol = 2e-5 if dt == "f32" else 1e-2
+    wtol = {"f32": 2e-5, "x3": 1e-4, "bf16": 1e-2}[dt]
     assert np.abs(dwg.cpu().numpy() - ref).max() / scale < wtol
     # split-K path + accumulation on top of existing content
-    L.conv_wgrad(xg, dyg, dwg, N=N, IH=H, IW=W, IC=IC, OH=OH, OW=OW, OC=OC, KH=k, KW=k, stride=s, dil=d, pad=pad, split_k=3)
+    L.conv_wgrad(xg, dyg, dwg, N=N, IH=H, IW=W, IC=IC, OH=OH, OW=OW, OC=OC, KH=k, KW=k, stride=s, dil=d, pad=pad, split_k=3, dtype=cdt)
     assert np.abs(dwg.cpu().numpy() - 2 * ref).max() / scale < 2 * wtol
 
 
@@ -281,6 +290,54 @@ def test_conv256_fwd_dgrad(case):
         L.conv_igemm(_nhwc(dy).to(dev, tdt), wt, dx7, N=N, IH=OH, IW=OW, IC=OC, OH=H, OW=W, OC=IC, KH=k, KW=k, stride=s, dil=d,
                      pad=pad, mode=1, bm_hint=224)
         np.testing.assert_allclose(dx7.float().cpu().numpy(), _nhwc(x.grad).numpy(), **tol)
+
+
+@pytest.mark.parametrize("case", CASES256)
+def test_conv256_split_bf16(case):
+    """The 256-tile kernel on f32 storage with split-bf16 products (dtype WSEG_F32X3): forward with the fused BN-ReLU second output
+    and a residual, data gradient with the masked-scale epilogue, on 256-row, 224-row and row-split tiles, against torch's f32 CPU
+    convolution at 1e-4 (the exact-f32 kernel: 2e-5; the bf16 kernel: 2e-2)."""
+    from wseg_amd import _lib as L
+    N, H, W, IC, OC, k, s, d = case
+    if IC % 32 != 0:
+        pytest.skip("split-bf16 packs need IC % 32 == 0")
+    pad = d * (k // 2)
+    OH = (H + 2 * pad - d * (k - 1) - 1) // s + 1
+    OW = (W + 2 * pad - d * (k - 1) - 1) // s + 1
+    x = _rand((N, IC, H, W), 1).requires_grad_(True)
+    w = _rand((OC, IC, k, k), 2, (2.0 / (IC * k * k)) ** 0.5).requires_grad_(True)
+    dy = _rand((N, OC, OH, OW), 3)
+    res = _rand((N, OC, OH, OW), 4)
+    scale, shift = _rand((OC,), 5) + 1.5, _rand((OC,), 6)
+    y = F.conv2d(x, w, None, s, pad, d)
+    y.backward(dy)
+    dev = "cuda"
+    xg = _nhwc(x.detach()).to(dev)
+    wm = w.detach().permute(0, 2, 3, 1).contiguous().to(dev)
+    wf32 = torch.empty(OC, k * k, IC, device=dev)
+    wt32 = torch.empty(IC, k * k, OC, device=dev)
+    L.pack_weights(wm, wf32, wt32, OC, k * k, IC, OC, IC, L.F32)
+    wf, wt = torch.empty_like(wf32), torch.empty_like(wt32)
+    L.pack_x3(wf32, wf); L.pack_x3(wt32, wt)
+    tol = dict(rtol=1e-4, atol=1e-4)
+    y_ref = _nhwc(y.detach() + res).numpy()
+    t_ref = _nhwc(torch.relu((y.detach() + res) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))).numpy()
+    for bm in (256, 224, 257, 128):
+        yg = torch.full((N, OH, OW, OC), float("nan"), device=dev)
+        tg = torch.full((N, OH, OW, OC), float("nan"), device=dev)
+        L.conv_igemm(xg, wf, yg, tg, N=N, IH=H, IW=W, IC=IC, OH=OH, OW=OW, OC=OC, KH=k, KW=k, stride=s, dil=d, pad=pad, bm_hint=bm,
+                     r_post=_nhwc(res).to(dev), scale=scale.to(dev), shift=shift.to(dev), dtype=L.F32X3)
+        np.testing.assert_allclose(yg.cpu().numpy(), y_ref, **tol)
+        np.testing.assert_allclose(tg.cpu().numpy(), t_ref, **tol)
+    if IC % 256 == 0:                     # dgrad: the conv's IC is the GEMM's N; BN-ReLU backward epilogue (mask = saved activation)
+        mask = _rand((N, IC, H, W), 7)
+        sc_in = _rand((IC,), 8) + 1.5
+        dx_ref = _nhwc(x.grad * sc_in.view(1, -1, 1, 1) * (mask > 0)).numpy()
+        for bm in (256, 224, 128):
+            dxg = torch.full((N, H, W, IC), float("nan"), device=dev)
+            L.conv_igemm(_nhwc(dy).to(dev), wt, dxg, N=N, IH=OH, IW=OW, IC=OC, OH=H, OW=W, OC=IC, KH=k, KW=k, stride=s, dil=d,
+                         pad=pad, mode=1, bm_hint=bm, epi=1, scale=sc_in.to(dev), mask=_nhwc(mask).to(dev), dtype=L.F32X3)
+            np.testing.assert_allclose(dxg.cpu().numpy(), dx_ref, **tol)
 
 
 def test_batched_transposed_pack_bf16_matches_f32_source():

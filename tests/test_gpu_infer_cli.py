@@ -10,7 +10,8 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def test_infer_matches_reference_fixture(golden_dir, proc_sd):
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3"])
+def test_infer_matches_reference_fixture(golden_dir, proc_sd, prec):
     from wseg_amd import synth
     from wseg_amd.infer import infer_image
     from wseg_amd.resnet38_contrast import Net
@@ -21,7 +22,7 @@ def test_infer_matches_reference_fixture(golden_dir, proc_sd):
     for si, s in enumerate([0.5, 1.0, 1.5, 2.0]):
         im = synth.synthetic_images(1, (int(np.round(H * s)), int(np.round(W * s))), 40 + si)
         imgs += [im, torch.flip(im, dims=[3])]
-    m = Net(precision="fp32"); m.load_state_dict(proc_sd); m.cuda(); m.eval()
+    m = Net(precision=prec); m.load_state_dict(proc_sd); m.cuda(); m.eval()
     norm_cam, pred, cam_dict = infer_image(m, imgs, lab, (H, W), 0.26)
     np.testing.assert_allclose(norm_cam.cpu().numpy(), g["norm_cam"], rtol=2e-4, atol=2e-5)
     mism = float((pred.cpu().numpy() != g["pred"]).mean())
@@ -34,12 +35,14 @@ MS_FIXTURES = ["infer_125x94", "infer_188x250", "infer_375x500"]     # odd sizes
 # reference's own winner / runner-up margin is inside f32 summation noise — the CAM gate of resnet38_contrast.py:46-48 zeroes every
 # entry below the per-pixel maximum, a discontinuous function, so two exact-f32 implementations that sum in a different order can
 # resolve a near-tie differently.  Such pixels are counted, bounded, and each one is CHECKED to be a near-tie.
-FP32_MAX_MISMATCH_FRACTION = 1e-4
-FP32_NEAR_TIE_MARGIN = 2e-3
+#   measured: fp32 1 / 0 / 17 px (8.5e-5, 0, 9.1e-5); bf16x3 (split-bf16 products, ~1e-5 forward deviation) 375x500: 307 px (1.64e-3)
+PARITY_MAX_MISMATCH_FRACTION = {"fp32": 1e-4, "bf16x3": 3.3e-3}
+PARITY_NEAR_TIE_MARGIN = {"fp32": 2e-3, "bf16x3": 2e-2}
 # bf16 (throughput mode): mismatching-pixel fraction against the reference's fp32 arg-max maps, bars = 2x the measured values (see the
 # test's printed line; procedural weights: near-threshold pixels of the alpha = 0.26 background score and of the class boundaries)
-BF16_MISMATCH_BAR = {"infer_125x94": None, "infer_188x250": None, "infer_375x500": None}
-BF16_MIOU_BAR = None
+#   measured on an MI355X: 125x94 0.01217 (143 px), 188x250 0.00894 (420 px), 375x500 0.04308 (8077 px)
+BF16_MISMATCH_BAR = {"infer_125x94": 0.025, "infer_188x250": 0.018, "infer_375x500": 0.087}
+BF16_MIOU_BAR = 89.8         # measured 94.907 over the 6 classes that occur in the reference's maps: bar = 100 - 2 x (100 - measured)
 
 
 def _msf_inputs(H, W, seed0):
@@ -68,7 +71,7 @@ def _write_eval_set(tmp_path, preds, gts, cams):
         np.save(tmp_path / "cam" / (name + ".npy"), cams[name], allow_pickle=True)
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3", "bf16"])
 def test_multiscale_inference_fixtures_and_cam_miou(golden_dir, proc_sd, tmp_path, prec):
     """contrast_infer.py:49-99 + eval.py:13-86 end to end on the HIP path: three multi-scale fixtures produced by the reference
     itself (odd sizes and a full 375 x 500 image: inputs up to 750 x 1000, 11 750 PCM pixels) -> infer_image -> the files
@@ -78,7 +81,7 @@ def test_multiscale_inference_fixtures_and_cam_miou(golden_dir, proc_sd, tmp_pat
     from wseg_amd import eval as weval
     from wseg_amd.infer import infer_image
     m = _net(proc_sd, prec)
-    preds, gts, cams, present, measured = {}, {}, {}, set([0]), {}
+    preds, gts, cams, present, measured, margins = {}, {}, {}, set([0]), {}, {}
     for name in MS_FIXTURES:
         g = np.load(os.path.join(golden_dir, name + ".npz"))
         H, W, seed0 = int(g["H"]), int(g["W"]), int(g["seed0"])
@@ -91,24 +94,28 @@ def test_multiscale_inference_fixtures_and_cam_miou(golden_dir, proc_sd, tmp_pat
         got = norm_cam.cpu().numpy()
         mism = float((pred != g["pred"]).mean())
         measured[name] = mism
-        if prec == "fp32":
+        if prec != "bf16":
             # every differing pixel must be a near-tie of our own map: top-1 and top-2 of [alpha, present classes] within the margin
             stack = np.concatenate([np.full((1, H, W), 0.26, np.float32), got[classes]], axis=0)
             top2 = np.sort(stack, axis=0)[-2:]
             margin = top2[1] - top2[0]
             bad = pred != g["pred"]
-            assert mism <= FP32_MAX_MISMATCH_FRACTION, (name, mism)
-            assert bad.sum() == 0 or float(margin[bad].max()) <= FP32_NEAR_TIE_MARGIN, (name, int(bad.sum()), float(margin[bad].max()))
-            np.testing.assert_allclose(got[classes][:, ::st, ::st], g["norm_cam_present"], rtol=5e-4, atol=5e-4)
-            np.testing.assert_allclose(got[classes].astype(np.float64).sum(axis=(1, 2)), g["sums"], rtol=2e-4)
+            margins[name] = float(margin[bad].max()) if bad.sum() else 0.0
+            assert mism <= PARITY_MAX_MISMATCH_FRACTION[prec], (name, mism)
+            assert margins[name] <= PARITY_NEAR_TIE_MARGIN[prec], (name, int(bad.sum()), margins[name])
+            vt = {"fp32": 5e-4, "bf16x3": 1e-2}[prec]       # (the CAM gate is discontinuous: measured 2e-4 / 3.3e-3 on the 375 x 500 image)
+            np.testing.assert_allclose(got[classes][:, ::st, ::st], g["norm_cam_present"], rtol=vt, atol=vt)
+            np.testing.assert_allclose(got[classes].astype(np.float64).sum(axis=(1, 2)), g["sums"], rtol=vt)
         absent = [c for c in range(20) if c not in classes]
         assert float(np.abs(got[absent] - (-1.0)).max()) <= 1e-6                # label gating: absent classes are the constant -1
         preds[name], gts[name] = pred, g["pred"]
         cams[name] = {k: v.cpu().numpy() for k, v in cam_dict.items()}
-        present |= set(int(c) + 1 for c in classes)
+        present |= set(int(c) for c in np.unique(g["pred"]))             # classes that occur in the ground truth (= the reference's maps)
     print(f"{prec}: arg-max mismatch fraction vs the reference's maps: " + ", ".join(f"{k} {v:.6f} ({int(round(v * preds[k].size))} px)" for k, v in measured.items()))
     if prec == "bf16":
         assert all(measured[k] <= BF16_MISMATCH_BAR[k] for k in MS_FIXTURES), measured
+    else:
+        print(f"{prec}: largest top-1 / top-2 margin among the differing pixels: {margins}")
     _write_eval_set(tmp_path, preds, gts, cams)
     res = weval.do_eval(MS_FIXTURES, str(tmp_path / "pred"), str(tmp_path / "gt"), "png")
     res_npy = weval.do_eval(MS_FIXTURES, str(tmp_path / "cam"), str(tmp_path / "gt"), "npy", 0.26)
@@ -118,9 +125,10 @@ def test_multiscale_inference_fixtures_and_cam_miou(golden_dir, proc_sd, tmp_pat
           f"(21-class mean as eval.py prints it: {res['mIoU']:.3f})")
     for k in res:                                                               # the .npy route (threshold 0.26 = alpha) is the same arg-max
         assert abs(res[k] - res_npy[k]) <= 1e-9, k
-    if prec == "fp32":
-        assert all(v >= 100.0 - 100.0 * 21 * FP32_MAX_MISMATCH_FRACTION for v in ious), ious     # = 100 when no near-tie pixel differs
-        assert miou_present >= 99.99, miou_present
+    if prec != "bf16":
+        floor = 100.0 - 100.0 * 21 * PARITY_MAX_MISMATCH_FRACTION[prec]
+        assert all(v >= floor for v in ious), ious                              # = 100 when no near-tie pixel differs
+        assert miou_present >= floor, miou_present
     else:
         assert miou_present >= BF16_MIOU_BAR, miou_present
 

@@ -39,13 +39,15 @@ def _trainer(proc_sd, precision, loss_impl, n, seed, py_seed, lr=0.01):
     return model, opt, tr
 
 
-@pytest.mark.parametrize("loss_impl", ["hip", "aten"])
+@pytest.mark.parametrize("loss_impl,prec", [("hip", "fp32"), ("aten", "fp32"), ("hip", "bf16x3")])
 @pytest.mark.parametrize("name", ["step_S160_N2", "step_S128_N3", "step_edge_S64_N3"])
-def test_step_matches_reference_fixture(golden_dir, proc_sd, name, loss_impl):
+def test_step_matches_reference_fixture(golden_dir, proc_sd, name, loss_impl, prec):
+    """prec bf16x3: the SAME bars (north-star tolerance 1e-4 on the scalars) with every conv / weight-gradient product computed as
+    split-bf16 (3 bf16 MFMAs, 16-17 operand bits) instead of the exact-f32 MFMA."""
     from wseg_amd import synth
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     n, size, seed, py_seed = int(g["n"]), int(g["size"]), int(g["seed"]), int(g["py_seed"])
-    model, opt, tr = _trainer(proc_sd, "fp32", loss_impl, n, seed, py_seed)
+    model, opt, tr = _trainer(proc_sd, prec, loss_impl, n, seed, py_seed)
     w_before = model._engine.conv_param("fc8").detach().clone() if model._engine.flat_w is not None else None
     lab = torch.from_numpy(g["label"]) if "label" in g.files else synth.synthetic_labels(n, seed)   # (edge fixture: an image with no
     got = tr.step(synth.synthetic_images(n, size, seed).cuda(), lab.cuda())                            #  class, one with all twenty)
@@ -59,11 +61,15 @@ def test_step_matches_reference_fixture(golden_dir, proc_sd, name, loss_impl):
     # their layer's largest gradient (scripts/relu_near_ties.py), and which of them flip depends on the summation order, so
     # its backbone bar is 5e-2 — a mishandled empty / full label row would show in the scalars and the head gradients.
     head = ("fc8.", "fc_proj.", "f9.", "f8_3.", "f8_4.")
+    # split-bf16 mode: its forward differs from the reference's by ~1e-5 instead of ~1e-7, so MORE ReLU pre-activations near zero resolve
+    # differently than in the reference (the effect the edge fixture shows in fp32) — the arithmetic itself is held to 2e-3 by
+    # test_gradients_under_the_hip_paths_relu_decisions[bf16x3]; measured worst slice error 1.1e-2 (profiles/r02_bf16x3_deviation.json)
+    wide = 5e-2 if "edge" in name else (2.5e-2 if prec == "bf16x3" else 2e-3)
     for key in g.files:
         if not key.startswith("gslice/"):
             continue
         k = key[len("gslice/"):]
-        tol = 5e-2 if ("edge" in name and not k.startswith(head)) else 2e-3
+        tol = 2e-3 if k.startswith(head) else wide
         gr = params[k].grad.detach().cpu()
         flat = gr.reshape(-1)
         stepv = max(1, flat.numel() // 4096)
@@ -109,8 +115,10 @@ def gates_from_ctx(S):
     return out
 
 
-def test_edge_fixture_gradients_under_the_hip_paths_relu_decisions(golden_dir, proc_sd):
-    """Why the edge fixture's backbone gradients are held to 5e-2 against the reference and not 2e-3: its all-twenty-classes
+@pytest.mark.parametrize("name,prec", [("step_edge_S64_N3", "fp32"), ("step_S160_N2", "bf16x3"), ("step_edge_S64_N3", "bf16x3")])
+def test_gradients_under_the_hip_paths_relu_decisions(golden_dir, proc_sd, name, prec):
+    """(also run in the split-bf16 mode, whose ~1e-5 forward deviation flips more near-zero pre-activations than exact f32 does.)
+    Why the edge fixture's backbone gradients are held to 5e-2 against the reference and not 2e-3: its all-twenty-classes
     image puts ReLU pre-activations within f32 summation noise of zero under large gradients, and which of them pass depends on
     the summation order (scripts/relu_near_ties.py).  Demonstrated here rather than argued: the CPU oracle re-run with the HIP
     path's OWN ReLU decisions injected (every backbone / head ReLU site, both views) must reproduce the HIP gradients at the
@@ -119,12 +127,11 @@ def test_edge_fixture_gradients_under_the_hip_paths_relu_decisions(golden_dir, p
     from oracle import loss as oloss
     from oracle import net as onet
     from wseg_amd import synth
-    name = "step_edge_S64_N3"
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     n, size, seed, py_seed = int(g["n"]), int(g["size"]), int(g["seed"]), int(g["py_seed"])
-    model, opt, tr = _trainer(proc_sd, "fp32", "hip", n, seed, py_seed)
+    model, opt, tr = _trainer(proc_sd, prec, "hip", n, seed, py_seed)
     model._engine.capture_ctx = True
-    lab = torch.from_numpy(g["label"])
+    lab = torch.from_numpy(g["label"]) if "label" in g.files else synth.synthetic_labels(n, seed)
     img = synth.synthetic_images(n, size, seed)
     got = tr.step(img.cuda(), lab.cuda())
     gates = gates_from_ctx(model._engine.last_ctx)
@@ -148,7 +155,7 @@ def test_edge_fixture_gradients_under_the_hip_paths_relu_decisions(golden_dir, p
         fix = g["gslice/" + k]
         stepv = max(1, a.numel() // 4096)
         flipped += int(np.abs(a[::stepv][:4096].numpy() - fix).max() / (np.abs(fix).max() + 1e-12) > 2e-3)
-    print(f"edge fixture: {flipped} of {len(GRAD_KEYS)} keys differ from the reference fixture by more than 2e-3 (none from the gate-injected oracle)")
+    print(f"{name} [{prec}]: {flipped} of {len(GRAD_KEYS)} keys differ from the reference fixture by more than 2e-3 (none from the gate-injected oracle)")
 
 
 def _multistep(proc_sd, g, prec, loss_impl="hip"):
@@ -185,13 +192,14 @@ def _multistep(proc_sd, g, prec, loss_impl="hip"):
     return scal, dw
 
 
-def test_three_steps_match_reference_fixture(golden_dir, proc_sd):
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3"])
+def test_three_steps_match_reference_fixture(golden_dir, proc_sd, prec):
     """contrast_train.py:397-399 + tool/torchutils.py:23-33 end to end, three consecutive iterations of the reference's own loop
     (oracle/make_goldens.py `multistep_golden`): pins the momentum buffer (first step buf = d, then 5e-4 * buf + d), the poly LR
     (new images, masks and lr each step), the flat-weight buffer <-> pack refresh between steps.  fp32: the 8 scalars of every
     step at 1e-4 and the weight DELTA after step 3 at 2e-3 of its maximum."""
     g = np.load(os.path.join(golden_dir, "step_S128_N3_x3.npz"))
-    scal, dw = _multistep(proc_sd, g, "fp32")
+    scal, dw = _multistep(proc_sd, g, prec)
     for s_ in range(int(g["steps"])):
         for k in SCALARS:
             ref = float(g[f"s{s_}/{k}"])

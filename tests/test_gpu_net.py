@@ -27,7 +27,7 @@ def _rel(a, b):
 def nets(proc_sd):
     from wseg_amd.resnet38_contrast import Net
     out = {}
-    for prec in ("fp32", "bf16"):
+    for prec in ("fp32", "bf16", "bf16x3"):
         m = Net(precision=prec)
         m.load_state_dict(proc_sd)
         m.cuda()
@@ -35,14 +35,15 @@ def nets(proc_sd):
     return out
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("size,n", [((104, 72), 1), ((64, 64), 2)])
-def test_forward_eval_fp32(nets, proc_sd, size, n):
+def test_forward_eval_fp32(nets, proc_sd, size, n, prec):
     from oracle import net as onet
     from wseg_amd import synth
     x = synth.synthetic_images(n, size, 5)
     with torch.no_grad():
         ref = onet.net_forward(x, proc_sd, None)
-    m = nets["fp32"].eval()
+    m = nets[prec].eval()
     with torch.no_grad():
         got = m(x.cuda())
     names = ["cam", "cam_rv", "f_proj", "cam_rv_down"]
@@ -70,7 +71,7 @@ def test_forward_eval_bf16(nets, proc_sd):
     assert (ref[0].argmax(1) != got[0].cpu().argmax(1)).float().mean().item() < 0.05
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3", "bf16"])
 def test_train_forward_backward(nets, proc_sd, prec):
     from oracle import net as onet
     from wseg_amd import synth
@@ -85,7 +86,7 @@ def test_train_forward_backward(nets, proc_sd, prec):
     ws = _functional(ref, 3)
 
     def fun(outs):
-        if prec == "fp32":      # random linear functional: every output element gets a gradient
+        if prec != "bf16":      # random linear functional: every output element gets a gradient
             return sum((o * w.to(o.device)).sum() for o, w in zip(outs, ws))
         # bf16: a coherent functional (a random one cancels so strongly that rounding noise is
         # amplified ~10x; measured: scripts/diag_bf16_grads.py)
@@ -99,7 +100,7 @@ def test_train_forward_backward(nets, proc_sd, prec):
     m.zero_grad(set_to_none=True)
     m.set_dropout_masks([masks])
     got = m(x.cuda())
-    tol_f = 2e-4 if prec == "fp32" else 2.5e-1
+    tol_f = 2e-4 if prec != "bf16" else 2.5e-1
     for r, g in zip(ref, got):
         assert _rel(g.detach().float().cpu(), r.detach()) < tol_f
     fun(got).backward()
@@ -119,7 +120,7 @@ def test_train_forward_backward(nets, proc_sd, prec):
         err = float((gr - rg).norm() / (rg.norm() + 1e-20))
         worst[k] = err
     assert n_grad == 40
-    tol = 1e-3 if prec == "fp32" else 0.1
+    tol = {"fp32": 1e-3, "bf16x3": 3e-2, "bf16": 0.1}[prec]     # (bf16x3: measured 0.9-1.5e-2 under this random functional: ReLU decisions near zero, see test_gpu_loss.py)
     bad = {k: v for k, v in worst.items() if v > tol}
     assert not bad, bad
     # frozen prefix and BN get no gradients

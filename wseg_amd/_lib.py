@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libwseg_hip.so")
 
-F32, BF16 = 0, 1
+F32, BF16, F32X3 = 0, 1, 2      # F32X3: f32 tensors, conv / wgrad products as split-bf16 (hi.hi + lo.hi + hi.lo)
 PROFILE_WGRAD = None
 PROFILE = None        # set to a list by bench.py to collect (start_event, end_event, flops) per conv launch
 PROFILE_STRIDE = 1    # event-bracket launch i of step s only when (i + s) % stride == 0: an event pair costs ~10 us of
@@ -30,7 +30,7 @@ def _profile_sample():
     i = _profile_idx
     _profile_idx += 1
     return (i + _profile_phase) % max(1, PROFILE_STRIDE) == 0, i
-TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16}
+TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16, F32X3: torch.float32}
 
 
 class ConvDesc(C.Structure):
@@ -100,7 +100,7 @@ def dtype_code(t):
 def conv_igemm(inp, w, out=None, out2=None, *, N, IH, IW, IC, OH, OW, OC, KH, KW, stride=1, dil=1, pad=0,
                mode=0, epi=0, r_pre=None, r_post=None, mask=None, scale=None, shift=None, drop=None,
                ld_in=None, ld_out=None, ld_out2=None, ld_rpre=None, ld_rpost=None, ld_mask=None, relu_out2=1,
-               relu_lt=0, bm_hint=0, seg2=None, in2=None, ld_in2=None, IC2=0):
+               relu_lt=0, bm_hint=0, seg2=None, in2=None, ld_in2=None, IC2=0, dtype=None):
     d = ConvDesc()
     d.inp, d.w, d.out, d.out2 = _ptr(inp), _ptr(w), _ptr(out), _ptr(out2)
     d.r_pre, d.r_post, d.mask = _ptr(r_pre), _ptr(r_post), _ptr(mask)
@@ -109,7 +109,7 @@ def conv_igemm(inp, w, out=None, out2=None, *, N, IH, IW, IC, OH, OW, OC, KH, KW
     d.OH, d.OW, d.OC, d.ld_out, d.ld_out2 = OH, OW, OC, ld_out or OC, ld_out2 or OC
     d.ld_rpre, d.ld_rpost, d.ld_mask = ld_rpre or OC, ld_rpost or OC, ld_mask or OC
     d.KH, d.KW, d.stride, d.dil, d.pad = KH, KW, stride, dil, pad
-    d.mode, d.epi, d.dtype, d.relu_out2, d.relu_lt, d.bm_hint = mode, epi, dtype_code(inp), relu_out2, relu_lt, bm_hint
+    d.mode, d.epi, d.dtype, d.relu_out2, d.relu_lt, d.bm_hint = mode, epi, (dtype_code(inp) if dtype is None else dtype), relu_out2, relu_lt, bm_hint
     if seg2 is not None:                         # (IH2, IW2, OH2, OW2): second row segment, same N
         d.IH2, d.IW2, d.OH2, d.OW2 = seg2
     if in2 is not None:                          # two sources: w = [OC][KH*KW*IC + IC2]
@@ -133,13 +133,13 @@ def conv_igemm(inp, w, out=None, out2=None, *, N, IH, IW, IC, OH, OW, OC, KH, KW
 
 
 def conv_wgrad(x, dy, dw, *, N, IH, IW, IC, OH, OW, OC, KH, KW, stride=1, dil=1, pad=0,
-               ld_x=None, ld_dy=None, split_k=0, IC_dw=None, OC_dw=None, tile_hint=0, seg2=None):
+               ld_x=None, ld_dy=None, split_k=0, IC_dw=None, OC_dw=None, tile_hint=0, seg2=None, dtype=None):
     d = WgradDesc()
     d.x, d.dy, d.dw = _ptr(x), _ptr(dy), _ptr(dw)
     d.N, d.IH, d.IW, d.IC, d.ld_x = N, IH, IW, IC, ld_x or IC
     d.OH, d.OW, d.OC, d.ld_dy = OH, OW, OC, ld_dy or OC
     d.KH, d.KW, d.stride, d.dil, d.pad = KH, KW, stride, dil, pad
-    d.dtype, d.split_k = dtype_code(x), split_k
+    d.dtype, d.split_k = (dtype_code(x) if dtype is None else dtype), split_k
     d.IC_dw, d.OC_dw, d.tile_hint = IC_dw or IC, OC_dw or OC, tile_hint
     if seg2 is not None:
         d.IH2, d.IW2, d.OH2, d.OW2 = seg2
@@ -333,5 +333,7 @@ def gemm256_probe(A, B, Cout, M, N, K, variant=0):
 
 
 def to_bf16(inp, out): _call("wseg_to_bf16", _v(inp), _v(out), C.c_long(inp.numel()))
+def split_bf16(inp, hi, lo): _call("wseg_split_bf16", _v(inp), _v(hi), _v(lo), C.c_long(inp.numel()))
+def pack_x3(src, dst): _call("wseg_pack_x3", _v(src), _v(dst), C.c_long(src.numel()))
 def pcm_forward_bf16(Fb, Gb, cam_rv, den, N, hw): _call("wseg_pcm_forward_bf16", _v(Fb), _v(Gb), _v(cam_rv), _v(den), N, hw)
 def pcm_backward_bf16(Fb, Gb, d_cam_rv, cam_rv, den, DN, DNb, dFh, N, hw): _call("wseg_pcm_backward_bf16", _v(Fb), _v(Gb), _v(d_cam_rv), _v(cam_rv), _v(den), _v(DN), _v(DNb), _v(dFh), N, hw)

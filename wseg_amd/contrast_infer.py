@@ -28,7 +28,7 @@ def main(argv=None):
     parser.add_argument("--out_cam_pred_alpha", default=0.26, type=float)
     parser.add_argument("--crf_iters", default=10, type=float)
     parser.add_argument("--labels", default="voc12/cls_labels.npy", type=str)
-    parser.add_argument("--precision", default=None, choices=[None, "bf16", "fp32"])
+    parser.add_argument("--precision", default=None, choices=[None, "bf16", "fp32", "bf16x3"])
     args = parser.parse_args(argv)
     if args.out_crf is not None:
         raise SystemExit("--out_crf needs pydensecrf, which is not available offline (out of the accelerated path)")

@@ -45,7 +45,7 @@ def main(argv=None):
     parser.add_argument("--bg_threshold", default=0.20, type=float)
     parser.add_argument("--labels", default="voc12/cls_labels.npy", type=str)
     parser.add_argument("--synthetic", default=0, type=int)
-    parser.add_argument("--precision", default=None, choices=[None, "bf16", "fp32"])
+    parser.add_argument("--precision", default=None, choices=[None, "bf16", "fp32", "bf16x3"])
     parser.add_argument("--rng_parity", action="store_true")
     parser.add_argument("--seed", default=0, type=int)
     args = parser.parse_args(argv)

@@ -265,3 +265,63 @@ extern "C" int wseg_pack_transposed_batch_bf16(const void* mirror, void* out, co
   WSEG_LAUNCH_CHECK();
   return 0;
 }
+
+// ---- split-bf16 weight pack (dtype WSEG_F32X3): every group of 32 consecutive K elements of an f32 [rows][K] matrix becomes
+// [32 hi bf16 | 32 lo bf16] (hi = RNE bf16(w), lo = RNE bf16(w - hi)) in the same 128 bytes, so the conv kernel stages B tiles
+// with the f32 path's addressing and reads both parts as ready-made MFMA operands.  One thread per 4 elements.
+static __global__ void pack_x3_kernel(const float* src, unsigned char* dst, long nquads) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nquads) return;
+  const long g = idx >> 3;
+  const int q = (int)(idx & 7);
+  const float4 v = *reinterpret_cast<const float4*>(src + g * 32 + q * 4);
+  const float x[4] = {v.x, v.y, v.z, v.w};
+  unsigned short hi[4], lo[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    hi[e] = f32_to_bf16(x[e]);
+    lo[e] = f32_to_bf16(x[e] - bf16_to_f32(hi[e]));
+  }
+  *reinterpret_cast<uint2*>(dst + g * 128 + q * 8) = make_uint2((unsigned)hi[0] | ((unsigned)hi[1] << 16), (unsigned)hi[2] | ((unsigned)hi[3] << 16));
+  *reinterpret_cast<uint2*>(dst + g * 128 + 64 + q * 8) = make_uint2((unsigned)lo[0] | ((unsigned)lo[1] << 16), (unsigned)lo[2] | ((unsigned)lo[3] << 16));
+}
+
+extern "C" int wseg_pack_x3(const float* src, void* dst, long numel, void* stream) {
+  WSEG_CHECK(src && dst && numel > 0 && numel % 32 == 0 && (const void*)src != dst, "pack_x3: numel must be a positive multiple of 32, out of place");
+  const long nquads = numel / 4;
+  hipLaunchKernelGGL(pack_x3_kernel, dim3((unsigned)((nquads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, (unsigned char*)dst, nquads);
+  WSEG_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- f32 -> (hi, lo) bf16 planes, x = hi + lo to 16-17 bits (hi = RNE bf16(x), lo = RNE bf16(x - hi)): the split-bf16 mode's
+// weight gradients of the large layers run the bf16 pixel-reduction kernel three times on these planes (lo.hi + hi.lo + hi.hi
+// accumulate into dW), which is faster than splitting inside the f32-tile kernel.  8 elements per thread.
+static __global__ void split_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, long total) {
+  const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+  if (i + 7 < total) {
+    float v[8];
+    load8<WSEG_F32>(in, i, v);
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bf16_t h0 = f32_to_bf16(v[2 * j]), h1 = f32_to_bf16(v[2 * j + 1]);
+      h[j] = (unsigned)h0 | ((unsigned)h1 << 16);
+      l[j] = (unsigned)f32_to_bf16(v[2 * j] - bf16_to_f32(h0)) | ((unsigned)f32_to_bf16(v[2 * j + 1] - bf16_to_f32(h1)) << 16);
+    }
+    *reinterpret_cast<uint4*>(hi + i) = make_uint4(h[0], h[1], h[2], h[3]);
+    *reinterpret_cast<uint4*>(lo + i) = make_uint4(l[0], l[1], l[2], l[3]);
+  } else {
+    for (long k = i; k < total; ++k) {
+      const bf16_t h0 = f32_to_bf16(in[k]);
+      hi[k] = h0; lo[k] = f32_to_bf16(in[k] - bf16_to_f32(h0));
+    }
+  }
+}
+
+extern "C" int wseg_split_bf16(const float* in, void* hi, void* lo, long total, void* stream) {
+  WSEG_CHECK(in && hi && lo && total > 0, "split_bf16: bad arguments");
+  hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)((total / 8 + 256) / 256)), dim3(256), 0, (hipStream_t)stream, in, (bf16_t*)hi, (bf16_t*)lo, total);
+  WSEG_LAUNCH_CHECK();
+  return 0;
+}

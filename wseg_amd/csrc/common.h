@@ -37,6 +37,28 @@ template <> struct elem<WSEG_BF16> {
   __device__ static __forceinline__ void st(void* p, size_t i, float v) { ((bf16_t*)p)[i] = f32_to_bf16(v); }
 };
 
+template <> struct elem<WSEG_F32X3> : elem<WSEG_F32> {};   // f32 storage; only the conv / wgrad inner products differ
+
+// f32 x 8 -> (hi, lo) bf16 x 8 with x = hi + lo to 16-17 bits: hi = RNE bf16(x), lo = RNE bf16(x - hi)
+__device__ __forceinline__ void split_bf16x8(const f32x4& p0, const f32x4& p1, bf16x8& hi, bf16x8& lo) {
+  const float x[8] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const bf16_t h = f32_to_bf16(x[e]);
+    hi[e] = (short)h;
+    lo[e] = (short)f32_to_bf16(x[e] - bf16_to_f32(h));
+  }
+}
+
+__device__ __forceinline__ void split_bf16x8(const float (&x)[8], bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const bf16_t h = f32_to_bf16(x[e]);
+    hi[e] = (short)h;
+    lo[e] = (short)f32_to_bf16(x[e] - bf16_to_f32(h));
+  }
+}
+
 // 8 consecutive elements <-> 8 floats (16 B for bf16, 32 B for f32); p must be 16-B aligned.
 template <int DT> __device__ __forceinline__ void load8(const void* p, size_t i, float (&v)[8]);
 template <> __device__ __forceinline__ void load8<WSEG_F32>(const void* p, size_t i, float (&v)[8]) {
@@ -53,6 +75,7 @@ template <> __device__ __forceinline__ void load8<WSEG_BF16>(const void* p, size
     v[2 * j + 1] = __uint_as_float(w[j] & 0xFFFF0000u);
   }
 }
+template <> __device__ __forceinline__ void load8<WSEG_F32X3>(const void* p, size_t i, float (&v)[8]) { load8<WSEG_F32>(p, i, v); }
 template <int DT> __device__ __forceinline__ void store8(void* p, size_t i, const float (&v)[8]);
 template <> __device__ __forceinline__ void store8<WSEG_F32>(void* p, size_t i, const float (&v)[8]) {
   float4* q = reinterpret_cast<float4*>((float*)p + i);
@@ -66,6 +89,8 @@ template <> __device__ __forceinline__ void store8<WSEG_BF16>(void* p, size_t i,
     w[j] = (unsigned)f32_to_bf16(v[2 * j]) | ((unsigned)f32_to_bf16(v[2 * j + 1]) << 16);
   *reinterpret_cast<uint4*>((bf16_t*)p + i) = make_uint4(w[0], w[1], w[2], w[3]);
 }
+
+template <> __device__ __forceinline__ void store8<WSEG_F32X3>(void* p, size_t i, const float (&v)[8]) { store8<WSEG_F32>(p, i, v); }
 
 // async 16-byte global -> LDS copy (LDS destination = wave-uniform base + lane*16)
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {

@@ -190,17 +190,31 @@ __device__ __forceinline__ void epilogue_image(const wseg_conv_desc& d, int M, c
 // (raw 16-B vectors, 64 registers), so a tile's epilogue exposes two global-load latencies instead of one per step
 // (the per-step version: 7-8 x ~1.5 us of a ~100 us tile).  When r_pre and r_post are both present (never in this network),
 // r_post stays a per-step load; the per-image dropout factors (b6 / b7 only, L2-resident) too.
-__device__ __forceinline__ uint4 ldg16_bf16(const void* p, size_t i) { return *reinterpret_cast<const uint4*>((const bf16_t*)p + i); }
-__device__ __forceinline__ void unpack8_bf16(const uint4& a, float (&v)[8]) {
-  const unsigned w[4] = {a.x, a.y, a.z, a.w};
+// raw8<DT>: 8 consecutive channels as they lie in memory (bf16: one 16-B vector; f32 storage: two), requested early, unpacked late
+template <int DT> struct raw8;
+template <> struct raw8<WSEG_BF16> {
+  uint4 q;
+  __device__ __forceinline__ void load(const void* p, size_t i) { q = *reinterpret_cast<const uint4*>((const bf16_t*)p + i); }
+  __device__ __forceinline__ void unpack(float (&v)[8]) const {
+    const unsigned w[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
-  for (int j = 0; j < 4; ++j) { v[2 * j] = __uint_as_float(w[j] << 16); v[2 * j + 1] = __uint_as_float(w[j] & 0xFFFF0000u); }
-}
+    for (int j = 0; j < 4; ++j) { v[2 * j] = __uint_as_float(w[j] << 16); v[2 * j + 1] = __uint_as_float(w[j] & 0xFFFF0000u); }
+  }
+};
+template <> struct raw8<WSEG_F32X3> {
+  f32x4 q0, q1;
+  __device__ __forceinline__ void load(const void* p, size_t i) {
+    q0 = *reinterpret_cast<const f32x4*>((const float*)p + i); q1 = *reinterpret_cast<const f32x4*>((const float*)p + i + 4);
+  }
+  __device__ __forceinline__ void unpack(float (&v)[8]) const {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = q0[e]; v[4 + e] = q1[e]; }
+  }
+};
 
-template <int EPI, int NI, int I0, int NB>
+template <int EPI, int NI, int I0, int NB, int DT>
 __device__ __forceinline__ void wave_local_epilogue_batch(const Args& a, float* wimg, int lane, int mw0, int oc, bool col_ok,
                                                           const float (&sc)[8], const float (&sh)[8], const f32x4 (&acc)[NI][4]) {
-  constexpr int DT = WSEG_BF16;
   constexpr int WLD = 64 + 4;
   const wseg_conv_desc& d = a.d;
   const int frow = lane & 15, fk = lane >> 4;
@@ -213,7 +227,7 @@ __device__ __forceinline__ void wave_local_epilogue_batch(const Args& a, float* 
   const size_t res_ld = res_is_pre ? d.ld_rpre : d.ld_rpost;
   const bool has_res = has_pre || has_post;
   int mrow[NB][2]; bool ok[NB][2];
-  uint4 qres[NB][2], qmk[NB][2];
+  raw8<DT> qres[NB][2], qmk[NB][2];
 #pragma unroll
   for (int i = 0; i < NB; ++i)
 #pragma unroll
@@ -221,8 +235,8 @@ __device__ __forceinline__ void wave_local_epilogue_batch(const Args& a, float* 
       const int m = mw0 + (I0 + i) * 16 + vr + 8 * t;
       ok[i][t] = col_ok && m < a.M;
       mrow[i][t] = ok[i][t] ? (a.perm ? (int)perm_decode(a, m).true_row : m) : 0;
-      if (has_res) qres[i][t] = ldg16_bf16(res_p, (size_t)mrow[i][t] * res_ld + oc);
-      if (has_mask) qmk[i][t] = ldg16_bf16(d.mask, (size_t)mrow[i][t] * d.ld_mask + oc);
+      if (has_res) qres[i][t].load(res_p, (size_t)mrow[i][t] * res_ld + oc);
+      if (has_mask) qmk[i][t].load(d.mask, (size_t)mrow[i][t] * d.ld_mask + oc);
     }
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
@@ -251,7 +265,7 @@ __device__ __forceinline__ void wave_local_epilogue_batch(const Args& a, float* 
       }
       const size_t m = (size_t)mrow[i][t];
       float res[8];
-      if (has_res) unpack8_bf16(qres[i][t], res);
+      if (has_res) qres[i][t].unpack(res);
       if (has_pre) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += res[e];
@@ -283,7 +297,7 @@ __device__ __forceinline__ void wave_local_epilogue_batch(const Args& a, float* 
         }
       } else if constexpr (EPI == 1) {
         float mk[8];
-        if (has_mask) unpack8_bf16(qmk[i][t], mk);
+        if (has_mask) qmk[i][t].unpack(mk);
         float o[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -304,7 +318,16 @@ __device__ __forceinline__ void wave_local_epilogue_batch(const Args& a, float* 
   }
 }
 
-template <int EPI, int NI>
+template <int EPI, int NI, int DT, int I0, int NB>
+__device__ __forceinline__ void wave_local_epilogue_rec(const Args& a, float* wimg, int lane, int mw0, int oc, bool col_ok,
+                                                        const float (&sc)[8], const float (&sh)[8], const f32x4 (&acc)[NI][4]) {
+  if constexpr (I0 < NI) {
+    wave_local_epilogue_batch<EPI, NI, I0, (NI - I0 < NB ? NI - I0 : NB), DT>(a, wimg, lane, mw0, oc, col_ok, sc, sh, acc);
+    wave_local_epilogue_rec<EPI, NI, DT, I0 + NB, NB>(a, wimg, lane, mw0, oc, col_ok, sc, sh, acc);
+  }
+}
+
+template <int EPI, int NI, int DT = WSEG_BF16>
 __device__ __forceinline__ void wave_local_epilogue(const Args& a, char* smem, int wid, int lane, int mw0, int col0, int n0,
                                                     const f32x4 (&acc)[NI][4]) {
   const wseg_conv_desc& d = a.d;
@@ -316,10 +339,8 @@ __device__ __forceinline__ void wave_local_epilogue(const Args& a, char* smem, i
   const int oc = col_ok ? oc_raw : 0;
   float sc[8], sh[8];
   epilogue_coeffs(d, n0, col0 + vg * 8, sc, sh);
-  constexpr int NB = 4;
-  wave_local_epilogue_batch<EPI, NI, 0, NB>(a, wimg, lane, mw0, oc, col_ok, sc, sh, acc);
-  if constexpr (NI > NB) wave_local_epilogue_batch<EPI, NI, NB, (NI - NB < NB ? NI - NB : NB)>(a, wimg, lane, mw0, oc, col_ok, sc, sh, acc);
-  static_assert(NI <= 2 * NB, "two batches cover the tile");
+  constexpr int NB = DT == WSEG_BF16 ? 4 : 2;      // operand prefetch depth in steps (f32 storage: vectors are twice as wide)
+  wave_local_epilogue_rec<EPI, NI, DT, 0, NB>(a, wimg, lane, mw0, oc, col_ok, sc, sh, acc);
 }
 
 // BM = 128 (default) or 64 (few output pixels: twice the workgroups for the same work)
@@ -445,6 +466,31 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const Args a) {
       stage(cur ^ 1);
     }
     const char* base = smem + cur * STAGE;
+    if constexpr (DT == WSEG_F32X3) {
+      // split-bf16 products: the A tile is f32 (32 channels per 128-B row; lane (frow, fk) takes channels 8fk..8fk+7 = 16-B chunks
+      // 2fk, 2fk+1 and splits them into hi + lo), the B tile is the pre-split pack [32 hi | 32 lo] bf16 of the same 32 channels
+      // (chunks fk and 4+fk).  Three MFMAs per accumulator: lo.hi + hi.lo first, hi.hi last.
+      bf16x8 ah[AI], al[AI], bh[4], bl[4];
+#pragma unroll
+      for (int i = 0; i < AI; ++i) {
+        const f32x4 p0 = *reinterpret_cast<const f32x4*>(base + a_rd + i * 16 * ROWB + (((2 * fk) ^ sw) * 16));
+        const f32x4 p1 = *reinterpret_cast<const f32x4*>(base + a_rd + i * 16 * ROWB + (((2 * fk + 1) ^ sw) * 16));
+        split_bf16x8(p0, p1, ah[i], al[i]);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        bh[j] = *reinterpret_cast<const bf16x8*>(base + b_rd + j * 16 * ROWB + ((fk ^ sw) * 16));
+        bl[j] = *reinterpret_cast<const bf16x8*>(base + b_rd + j * 16 * ROWB + (((4 + fk) ^ sw) * 16));
+      }
+#pragma unroll
+      for (int i = 0; i < AI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    } else {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int off = ((ks * 4 + fk) ^ sw) * 16;
@@ -473,6 +519,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const Args a) {
             for (int j = 0; j < 4; ++j)
               acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
       }
+    }
     }
     __syncthreads();                               // next stage landed, this stage fully read
     cur ^= 1;
@@ -514,9 +561,13 @@ constexpr int HALF256 = 16384, TILE256 = 4 * HALF256;
 // the zero page and never read, phase 2 runs 3 row blocks instead of 4).  For the layers whose 256-row tiles fill the last
 // round of 256 CUs badly (424 tiles = 1.66 rounds for the 512-channel 56x56 layers) 486 tiles of 7/8 the work are 12.5 % less
 // time per CU; the host picks it when that arithmetic says so.
-template <int EPI, int STG, int NI = 8>
+// DT = WSEG_F32X3 (split-bf16 products on f32 storage): the same pipeline on f32 activation rows (32 channels per 128-B K-tile row,
+// split into hi + lo at fragment-read time) and the pre-split weight pack [32 hi | 32 lo]; the two fragment sets af[0] / af[1] and
+// b[0] / b[1] that hold the two K halves in bf16 mode hold (hi, lo) here, and a quadrant issues lo.hi + hi.lo + hi.hi.
+template <int EPI, int STG, int NI = 8, int DT = WSEG_BF16>
 __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const Args a) {
-  constexpr int ES = 2, CH = 8;
+  constexpr bool X3 = DT == WSEG_F32X3;
+  constexpr int ES = X3 ? 4 : 2, CH = 16 / ES;
   constexpr int RH = NI * 16, BMT = 2 * RH;        // rows per wave row / per tile
   static_assert(NI == 8 || (NI == 7 && STG >= 2), "224-row tiles exist for the 2-phase schedules only");
   __shared__ __attribute__((aligned(16))) char smem[2 * TILE256];
@@ -650,12 +701,23 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const Args a) {
 
   bf16x8 af[2][4], b0[2][2], b1[2][2];             // [ks][tile]: A sub-tile (64 rows), B sub-tiles hb = 0 / 1 (32 cols each)
   auto ldA = [&](const char* aH, int ha) {
+    if constexpr (X3) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (ha * 4 + i < NI) {
+          const char* row = aH + (ha * 64 + i * 16 + frow) * 128;
+          const f32x4 p0 = *reinterpret_cast<const f32x4*>(row + (((2 * fk) ^ sw) << 4));
+          const f32x4 p1 = *reinterpret_cast<const f32x4*>(row + (((2 * fk + 1) ^ sw) << 4));
+          split_bf16x8(p0, p1, af[0][i], af[1][i]);
+        }
+    } else {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         if (ha * 4 + i < NI)
           af[ks][i] = *reinterpret_cast<const bf16x8*>(aH + (ha * 64 + i * 16 + frow) * 128 + (((ks * 4 + fk) ^ sw) << 4));
+    }
   };
   auto ldB = [&](const char* bH, int hb, bf16x8 (&bf)[2][2]) {
 #pragma unroll
@@ -667,6 +729,16 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const Args a) {
 #define MFMA_Q(HA, HB, BF)                                                                                   \
   do {                                                                                                       \
     __builtin_amdgcn_s_setprio(1);                                                                           \
+    if constexpr (X3) {                                                                                      \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                          \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                        \
+          if ((HA) * 4 + i < NI) {                                                                           \
+            f32x4& c_ = acc[(HA) * 4 + i][(HB) * 2 + j];                                                     \
+            c_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][i], BF[0][j], c_, 0, 0, 0);                   \
+            c_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i], BF[1][j], c_, 0, 0, 0);                   \
+            c_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i], BF[0][j], c_, 0, 0, 0);                   \
+          }                                                                                                  \
+    } else                                                                                                   \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                         \
       _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                          \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                        \
@@ -766,7 +838,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const Args a) {
 
   // ---- epilogue, wave-local (see wave_local_epilogue)
   __syncthreads();                                 // every wave is done with the pipeline buffers
-  wave_local_epilogue<EPI, NI>(a, smem, wid, lane, m0 + wr * RH, wc * 64, n0, acc);
+  wave_local_epilogue<EPI, NI, DT>(a, smem, wid, lane, m0 + wr * RH, wc * 64, n0, acc);
 }
 
 
@@ -1105,7 +1177,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm512x128_kernel(const Args a)
 
 extern "C" int wseg_conv_igemm(const wseg_conv_desc* d, void* stream) {
   WSEG_CHECK(d && d->in && d->w && (d->out || d->out2), "conv_igemm: null pointer");
-  WSEG_CHECK(d->dtype == WSEG_F32 || d->dtype == WSEG_BF16, "conv_igemm: bad dtype %d", d->dtype);
+  WSEG_CHECK(d->dtype == WSEG_F32 || d->dtype == WSEG_BF16 || d->dtype == WSEG_F32X3, "conv_igemm: bad dtype %d", d->dtype);
   const int es = d->dtype == WSEG_BF16 ? 2 : 4;
   WSEG_CHECK((d->IC * es) % ROWB == 0, "conv_igemm: IC=%d must be a multiple of %d", d->IC, ROWB / es);
   WSEG_CHECK(d->OC % 8 == 0 && d->ld_in % 8 == 0, "conv_igemm: OC=%d / ld_in=%d must be multiples of 8", d->OC, d->ld_in);
@@ -1150,6 +1222,8 @@ extern "C" int wseg_conv_igemm(const wseg_conv_desc* d, void* stream) {
   do {                                                                                                          \
     if (d->dtype == WSEG_BF16) {                                                                                \
       if (d->epi == 0) WSEG_LAUNCH_CONV1(WSEG_BF16, 0, BM_); else if (d->epi == 1) WSEG_LAUNCH_CONV1(WSEG_BF16, 1, BM_); else WSEG_LAUNCH_CONV1(WSEG_BF16, 2, BM_); \
+    } else if (d->dtype == WSEG_F32X3) {                                                                        \
+      if (d->epi == 0) WSEG_LAUNCH_CONV1(WSEG_F32X3, 0, BM_); else if (d->epi == 1) WSEG_LAUNCH_CONV1(WSEG_F32X3, 1, BM_); else WSEG_LAUNCH_CONV1(WSEG_F32X3, 2, BM_); \
     } else {                                                                                                    \
       if (d->epi == 0) WSEG_LAUNCH_CONV1(WSEG_F32, 0, BM_); else if (d->epi == 1) WSEG_LAUNCH_CONV1(WSEG_F32, 1, BM_); else WSEG_LAUNCH_CONV1(WSEG_F32, 2, BM_); \
     }                                                                                                           \
@@ -1157,7 +1231,7 @@ extern "C" int wseg_conv_igemm(const wseg_conv_desc* d, void* stream) {
   a.row0 = 0;
   // 256x256 phase-pipelined tiles (bf16, OC >= 256): chosen when the (1 workgroup / CU) rounds are full enough
   bool big = false;
-  if (d->dtype == WSEG_BF16 && d->OC % 256 == 0 && d->bm_hint != 64 && d->bm_hint != 128 && d->bm_hint != 258 && d->bm_hint != 259 && d->bm_hint >= 0) {   // (257: test hook, forces the row split)
+  if ((d->dtype == WSEG_BF16 || (d->dtype == WSEG_F32X3 && d->in2 == nullptr)) && d->OC % 256 == 0 && d->bm_hint != 64 && d->bm_hint != 128 && d->bm_hint != 258 && d->bm_hint != 259 && d->bm_hint >= 0) {   // (257: test hook, forces the row split)
     const long t256 = ((M + 255) / 256) * ((d->OC + 255) / 256);
     const long rounds = (t256 + 255) / 256;
     static const int auto256 = getenv("WSEG_CONV256") ? atoi(getenv("WSEG_CONV256")) : 1;   // (0: A/B switch)
@@ -1246,7 +1320,16 @@ extern "C" int wseg_conv_igemm(const wseg_conv_desc* d, void* stream) {
     else if (d->epi == 1) hipLaunchKernelGGL((conv_igemm256_kernel<1, STG_>), dim3(a.nwg), dim3(512), 0, s, a);         \
     else hipLaunchKernelGGL((conv_igemm256_kernel<2, STG_>), dim3(a.nwg), dim3(512), 0, s, a);                          \
   } while (0)
-    if (ni7) {
+    if (d->dtype == WSEG_F32X3) {                   // split-bf16 products: the 2-phase ping-pong schedule only
+#define WSEG_LAUNCH_256X3(NI_)                                                                                                          \
+  do {                                                                                                                                  \
+    if (d->epi == 0) hipLaunchKernelGGL((conv_igemm256_kernel<0, 2, NI_, WSEG_F32X3>), dim3(a.nwg), dim3(512), 0, s, a);                 \
+    else if (d->epi == 1) hipLaunchKernelGGL((conv_igemm256_kernel<1, 2, NI_, WSEG_F32X3>), dim3(a.nwg), dim3(512), 0, s, a);            \
+    else hipLaunchKernelGGL((conv_igemm256_kernel<2, 2, NI_, WSEG_F32X3>), dim3(a.nwg), dim3(512), 0, s, a);                             \
+  } while (0)
+      if (ni7) WSEG_LAUNCH_256X3(7); else WSEG_LAUNCH_256X3(8);
+#undef WSEG_LAUNCH_256X3
+    } else if (ni7) {
       if (stagger == 2) {
         if (d->epi == 0) hipLaunchKernelGGL((conv_igemm256_kernel<0, 2, 7>), dim3(a.nwg), dim3(512), 0, s, a);
         else if (d->epi == 1) hipLaunchKernelGGL((conv_igemm256_kernel<1, 2, 7>), dim3(a.nwg), dim3(512), 0, s, a);

@@ -223,6 +223,38 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void conv_wgrad_kernel(const Args 
           for (int j = 0; j < NJ; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
       }
+    } else if constexpr (DT == WSEG_F32X3) {
+      // split-bf16 products on f32 operands: lane (fcol, fk) gathers the 8 pixels 4e + fk (e = 0..7) of its channel of both
+      // operands (the scalar reads of the f32 path, same swizzle), splits them into hi + lo and issues lo.hi + hi.lo + hi.hi
+      float a8[MI][8], b8[NJ][8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int row = e * 4 + fk;
+        const int s = row & 7;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const int blk = wr * MI + i;
+          a8[i][e] = *reinterpret_cast<const float*>(bo + row * ROWB_O + (((blk & ~7) | ((blk ^ s) & 7)) << 6) + fcol * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int blk = wc * NJ + j;
+          b8[j][e] = *reinterpret_cast<const float*>(bi + row * ROWB_I + (((blk & ~7) | ((blk ^ s) & 7)) << 6) + fcol * 4);
+        }
+      }
+      bf16x8 ah[MI], al[MI], bh[NJ], bl[NJ];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) split_bf16x8(a8[i], ah[i], al[i]);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) split_bf16x8(b8[j], bh[j], bl[j]);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
     } else {
 #pragma unroll
       for (int kk = 0; kk < PK / 4; ++kk) {
@@ -734,7 +766,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pipe_kernel(const Args a) {
 
 extern "C" int wseg_conv_wgrad(const wseg_wgrad_desc* d, void* stream) {
   WSEG_CHECK(d && d->x && d->dy && d->dw, "conv_wgrad: null pointer");
-  WSEG_CHECK(d->dtype == WSEG_F32 || d->dtype == WSEG_BF16, "conv_wgrad: bad dtype");
+  WSEG_CHECK(d->dtype == WSEG_F32 || d->dtype == WSEG_BF16 || d->dtype == WSEG_F32X3, "conv_wgrad: bad dtype");
   WSEG_CHECK(d->IC % 8 == 0 && d->OC % 8 == 0 && d->ld_x % 8 == 0 && d->ld_dy % 8 == 0,
              "conv_wgrad: IC/OC/ld must be multiples of 8 (IC=%d OC=%d ld_x=%d ld_dy=%d)", d->IC, d->OC, d->ld_x, d->ld_dy);
   WSEG_CHECK(d->ld_x >= d->IC && d->ld_dy >= d->OC, "conv_wgrad: leading dims too small");
@@ -809,6 +841,8 @@ extern "C" int wseg_conv_wgrad(const wseg_wgrad_desc* d, void* stream) {
     hipLaunchKernelGGL((conv_wgrad_kernel<WSEG_BF16, 256, 256, 2, 4>), grid, dim3(512), 0, s, a);
   else if (d->dtype == WSEG_BF16)
     hipLaunchKernelGGL((conv_wgrad_kernel<WSEG_BF16, 128, 128, 2, 2>), grid, dim3(256), 0, s, a);
+  else if (d->dtype == WSEG_F32X3)
+    hipLaunchKernelGGL((conv_wgrad_kernel<WSEG_F32X3, 128, 128, 2, 2>), grid, dim3(256), 0, s, a);
   else
     hipLaunchKernelGGL((conv_wgrad_kernel<WSEG_F32, 128, 128, 2, 2>), grid, dim3(256), 0, s, a);
   WSEG_LAUNCH_CHECK();

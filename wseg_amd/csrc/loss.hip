@@ -860,6 +860,7 @@ struct NceArgs { NceView v[2]; int nviews, P; float coef_cross, coef_intra; floa
 
 // similarities of 16 pixels (rows grp16*16 ..) to the 42 prototypes held in pb; returns acc[t][r] = S[pixel 4g+r][class t*16+col]
 // already divided by the pixel's norm, and the lane's own row norm in `nr` (row = lane & 15)
+template <int NT = 3>   // NT = 2: only the first 32 classes (the record pass needs the own-view prototypes only)
 __device__ __forceinline__ void nce_sims16(const float* __restrict__ F, int P, int grp16, int col, int g, const f32x4 (&pb)[3][8],
                                            f32x4 (&acc)[3], float& nr) {
   const int row = grp16 * 16 + col;
@@ -878,7 +879,7 @@ __device__ __forceinline__ void nce_sims16(const float* __restrict__ F, int P, i
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
-      for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[b][e], pb[t][b][e], acc[t], 0, 0, 0);
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[b][e], pb[t][b][e], acc[t], 0, 0, 0);
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const float ir = __shfl(inv, 4 * g + r, 64);
@@ -907,7 +908,7 @@ __global__ __launch_bounds__(256) void nce_records_kernel(const NceArgs a) {
       f32x4 pb[3][8];
       nce_load_protos(v.p_own, nullptr, col, g, pb);
       f32x4 acc[3]; float nr;
-      nce_sims16(v.F, P, grp, col, g, pb, acc, nr);
+      nce_sims16<2>(v.F, P, grp, col, g, pb, acc, nr);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int p = grp * 16 + 4 * g + r;

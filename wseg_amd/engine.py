@@ -23,6 +23,14 @@ FUSE_SKIP = os.environ.get("WSEG_FUSE_SKIP", "1") != "0"   # bottleneck skip con
 FEAT_LD = 256          # PCM feature rows: [f8_3 64 | f8_4 128 | x_s 3 | zero pad 61]
 
 
+DT_OF = {"bf16": L.BF16, "fp32": L.F32, "bf16x3": L.F32X3}   # bf16x3: f32 storage, conv / wgrad products as split-bf16 (3 bf16 MFMAs)
+
+
+def _cdt(dt):
+    """dtype override for the conv / wgrad launches: the split-bf16 mode runs on f32 tensors."""
+    return L.F32X3 if dt == L.F32X3 else None
+
+
 def _out_size(h, k, s, d):
     p = d * (k // 2)
     return (h + 2 * p - d * (k - 1) - 1) // s + 1
@@ -185,6 +193,14 @@ class Engine:
         shift = (bn.bias.detach().float() - bn.running_mean.float() * scale).to(device)
         return scale.contiguous(), shift.contiguous()
 
+    @staticmethod
+    def _x3(w32):
+        """Split-bf16 pack of an f32 weight pack [rows][K] (K % 32 == 0): per 32 K-elements [32 hi | 32 lo] bf16 in the same bytes
+        (kept in a float32-typed tensor of the same shape: only the conv kernels of dtype F32X3 read it)."""
+        out = torch.empty_like(w32)
+        L.pack_x3(w32.contiguous(), out)
+        return out
+
     def ensure_packs(self, device, dt, defer_wt=False):
         with self.lock:
             return self._ensure_packs(device, dt, defer_wt)
@@ -208,8 +224,8 @@ class Engine:
                 if b[0] in arch.FROZEN_BLOCKS:
                     for (cname, ci, co, k, s, d) in arch.block_convs(b):
                         wf = torch.empty(co, k * k, ci, device=device, dtype=tdt)
-                        L.pack_weights(self.conv_param(cname).detach(), wf, None, co, k * k, ci, co, ci, dt)
-                        F_["w"][cname] = wf
+                        L.pack_weights(self.conv_param(cname).detach(), wf, None, co, k * k, ci, co, ci, L.F32 if dt == L.F32X3 else dt)
+                        F_["w"][cname] = self._x3(wf) if dt == L.F32X3 else wf
             F_["bn"]["bn7"] = self._bn_fold("bn7", device)
             F_["w"]["conv1a_kc"] = net.conv1a.weight.detach().to(device).float().permute(2, 3, 1, 0).reshape(27, 64).contiguous()   # [k = (ky*3+kx)*3+ic][oc] for the packed-FMA stem
             self._frozen_packs, self._frozen_key = F_, fkey
@@ -231,6 +247,11 @@ class Engine:
                 self.flat_wb_version = self.flat_w_version
             self._mirror_pversions = tuple(self.conv_param(n_)._version for n_ in names)
             mirror = self.flat_wb
+        elif dt == L.F32X3:
+            if getattr(self, "flat_w3", None) is None or self.flat_w3.numel() != self.flat_w.numel() or self.flat_w3.device != device:
+                self.flat_w3 = torch.empty_like(self.flat_w)
+            L.pack_x3(self.flat_w, self.flat_w3)             # (every trainable tensor's rows are whole 32-element groups, f9 aside: it has its own pack)
+            mirror = self.flat_w3
         else:
             mirror = self.flat_w
         # transposed (dgrad) packs [IC][T][OC]: ONE flat buffer, ONE launch over all layers (same offsets as flat_w)
@@ -256,6 +277,8 @@ class Engine:
             self._wt_table64 = torch.tensor(rows64, dtype=torch.int64, device=device)
             self._wt_tiles64 = t64
         self._wt_pending = (dt, mirror)
+        if dt == L.F32X3 and (getattr(self, "flat_wt3", None) is None or self.flat_wt3.numel() != self.flat_w.numel() or self.flat_wt3.device != device):
+            self.flat_wt3 = torch.empty_like(self.flat_w)
         for b in arch.BLOCKS:
             if b[0] in arch.FROZEN_BLOCKS:
                 continue
@@ -264,7 +287,7 @@ class Engine:
                 off, n = self.offsets[cname]
                 P["w"][cname] = mirror[off:off + n].view(co, T, ci)
                 if cname not in no_dgrad:
-                    P["wt"][cname] = self.flat_wt[off:off + n].view(ci, T, co)
+                    P["wt"][cname] = (self.flat_wt3 if dt == L.F32X3 else self.flat_wt)[off:off + n].view(ci, T, co)
         # bottleneck blocks (b6, b7), bf16 mode: skip conv and last conv as ONE two-source product (K-concatenation):
         # rows [W_branch1[oc] | W_branch2b2[oc]] — the skip output is then neither written nor re-read (444 MB each way for b7)
         if dt == L.BF16 and FUSE_SKIP:
@@ -279,10 +302,13 @@ class Engine:
         # fused head: rows [fc_proj | fc8 | 0]; its transposed pack is made from the two f32 masters directly
         wh = torch.zeros(HEAD_LD, 1, 4096, device=device, dtype=tdt)
         wht = torch.zeros(4096, 1, HEAD_LD, device=device, dtype=tdt)
-        L.pack_weights(net.fc_proj.weight.detach(), wh, None, 128, 1, 4096, 128, 4096, dt)
-        L.pack_weights(net.fc8.weight.detach(), wh[128:], None, 21, 1, 4096, 21, 4096, dt)
+        pdt = L.F32 if dt == L.F32X3 else dt                  # (split-bf16: f32 packs first, split below)
+        L.pack_weights(net.fc_proj.weight.detach(), wh, None, 128, 1, 4096, 128, 4096, pdt)
+        L.pack_weights(net.fc8.weight.detach(), wh[128:], None, 21, 1, 4096, 21, 4096, pdt)
         off, _ = self.offsets["fc_proj"]                     # fc_proj and fc8 are adjacent in flat_w: one [149,4096] master
-        L.pack_weights(self.flat_w[off:off + 149 * 4096], None, wht, 149, 1, 4096, HEAD_LD, 4096, dt)
+        L.pack_weights(self.flat_w[off:off + 149 * 4096], None, wht, 149, 1, 4096, HEAD_LD, 4096, pdt)
+        if dt == L.F32X3:
+            wh, wht = self._x3(wh), self._x3(wht)
         P["w"]["head"], P["wt"]["head"] = wh, wht
         for nm, (co, ci) in (("f8_3", (64, 512)), ("f8_4", (128, 1024))):
             off, n = self.offsets[nm]
@@ -292,7 +318,9 @@ class Engine:
         w9p = torch.cat([w9[:, 3:67], w9[:, 67:195], w9[:, 0:3]], dim=1).contiguous()
         wf = torch.empty(192, 1, FEAT_LD, device=device, dtype=tdt)
         wt = torch.empty(FEAT_LD, 1, 192, device=device, dtype=tdt)
-        L.pack_weights(w9p, wf, wt, 192, 1, 195, 192, FEAT_LD, dt)
+        L.pack_weights(w9p, wf, wt, 192, 1, 195, 192, FEAT_LD, pdt)
+        if dt == L.F32X3:
+            wf, wt = self._x3(wf), self._x3(wt)
         P["w"]["f9"], P["wt"]["f9"] = wf, wt
         self.packs, self.pack_key = P, key
         if not defer_wt:
@@ -312,7 +340,9 @@ class Engine:
         if dt == L.BF16:                                     # from the bf16 mirror (written by the fused SGD): a third of the traffic
             L.pack_transposed_batch_bf16(mirror, self.flat_wt, self._wt_table64, self._wt_table64.shape[0], self._wt_tiles64)
         else:
-            L.pack_transposed_batch(self.flat_w, self.flat_wt, self._wt_table, self._wt_table.shape[0], self._wt_tiles, dt)
+            L.pack_transposed_batch(self.flat_w, self.flat_wt, self._wt_table, self._wt_table.shape[0], self._wt_tiles, L.F32 if dt == L.F32X3 else dt)
+            if dt == L.F32X3:
+                L.pack_x3(self.flat_wt, self.flat_wt3)
         for b in arch.BLOCKS:
             nm, cin_, mid_, cout_ = b[0], b[2], b[3], b[4]
             if (nm + ".skip_fused") not in P["w"]:
@@ -373,7 +403,7 @@ class Engine:
         V = len(xs)
         assert V in (1, 2)
         dev = xs[0].device
-        dt = L.BF16 if net.precision == "bf16" else L.F32
+        dt = DT_OF[net.precision]
         tdt = L.TORCH_DTYPE[dt]
         P = self.ensure_packs(dev, dt)
         N = xs[0].shape[0]
@@ -397,7 +427,7 @@ class Engine:
         def conv(inp, wname, out, out2, cin, cout, k, stride, dil, din, dout, **kw):
             seg2 = (din[1][0], din[1][1], dout[1][0], dout[1][1]) if V == 2 else None
             L.conv_igemm(inp, P["w"][wname], out, out2, N=N, IH=din[0][0], IW=din[0][1], IC=cin, OH=dout[0][0], OW=dout[0][1],
-                         OC=cout, KH=k, KW=k, stride=stride, dil=dil, pad=dil * (k // 2), seg2=seg2, **kw)
+                         OC=cout, KH=k, KW=k, stride=stride, dil=dil, pad=dil * (k // 2), seg2=seg2, dtype=_cdt(dt), **kw)
 
         def next_bn(i):
             if i + 1 < len(arch.BLOCKS):
@@ -408,7 +438,7 @@ class Engine:
         sc, sh = P["bn"]["b2.bn_branch2a"]
         t = E(rows_of(dims), 64)
         for x, off, (H, W) in zip(xs, offs_of(dims), dims):
-            L.stem_conv_kc(x, P["w"]["conv1a_kc"], sc, sh, None, t[off:], N, H, W, dt)
+            L.stem_conv_kc(x, P["w"]["conv1a_kc"], sc, sh, None, t[off:], N, H, W, L.F32 if dt == L.F32X3 else dt)
         xraw = None
         for i, b in enumerate(arch.BLOCKS):
             name, kind, cin, mid, cout, stride, fd, d, p = b
@@ -558,18 +588,42 @@ class Engine:
             wstream.wait_stream(main)
         keep = []
 
+        planes = {}                                          # split-bf16 mode: (hi, lo) bf16 planes of an f32 operand, made once per tensor
+
+        def split(t_):
+            key = (t_.data_ptr(), t_.numel())
+            if key not in planes:
+                hi, lo = torch.empty(t_.shape, device=dev, dtype=torch.bfloat16), torch.empty(t_.shape, device=dev, dtype=torch.bfloat16)
+                L.split_bf16(t_, hi, lo)
+                planes[key] = (hi, lo, t_)                   # (keeps the source alive: the key is its address)
+            return planes[key][:2]
+
+        def wgrad_launch(x, dy, dw, big_x3, **args):
+            if big_x3:
+                # split-bf16 products on the bf16 pixel-reduction kernel: dW += X_lo^T dY_hi + X_hi^T dY_lo + X_hi^T dY_hi (it accumulates
+                # with float atomics anyway) — 3 launches at the bf16 kernel's rate beat one launch of the f32-tile kernel that splits inside
+                (xh, xl), (dh, dl) = split(x), split(dy)
+                args = dict(args, dtype=None)
+                L.conv_wgrad(xl, dh, dw, **args)
+                L.conv_wgrad(xh, dl, dw, **args)
+                L.conv_wgrad(xh, dh, dw, **args)
+            else:
+                L.conv_wgrad(x, dy, dw, **args)
+
         def wgrad(nm, x, dy, cin, cout, k, stride, dil, din, dout, **kw):
             if trainable(nm):
                 off, n = self.offsets[nm]
                 args = dict(N=N, IH=din[0][0], IW=din[0][1], IC=cin, OH=dout[0][0], OW=dout[0][1],
-                            OC=cout, KH=k, KW=k, stride=stride, dil=dil, pad=dil * (k // 2), seg2=seg(din, dout), **kw)
+                            OC=cout, KH=k, KW=k, stride=stride, dil=dil, pad=dil * (k // 2), seg2=seg(din, dout), dtype=_cdt(dt), **kw)
+                big_x3 = dt == L.F32X3 and cin >= 256 and cout >= 256 and not kw and x.is_contiguous() and dy.is_contiguous() \
+                    and x.shape[1] == cin and dy.shape[1] == cout
                 if wstream is None:
-                    L.conv_wgrad(x, dy, self.flat_g[off:off + n], **args)
+                    wgrad_launch(x, dy, self.flat_g[off:off + n], big_x3, **args)
                 else:
                     keep.append((x, dy))
                     wstream.wait_event(main.record_event())
                     with torch.cuda.stream(wstream):
-                        L.conv_wgrad(x, dy, self.flat_g[off:off + n], **args)
+                        wgrad_launch(x, dy, self.flat_g[off:off + n], big_x3, **args)
 
         def block_done(nm):
             """All weight gradients of block `nm` are enqueued: the data-parallel trainer may start reducing its bucket.  With a
@@ -583,7 +637,7 @@ class Engine:
             # in = dY over the conv's OUTPUT dims (dout), out = dX over its INPUT dims (din)
             seg2 = (dout[1][0], dout[1][1], din[1][0], din[1][1]) if V == 2 else None
             L.conv_igemm(dy, P["wt"][wname], out, None, N=N, IH=dout[0][0], IW=dout[0][1], IC=conv_cout, OH=din[0][0], OW=din[0][1],
-                         OC=conv_cin, KH=k, KW=k, stride=stride, dil=dil, pad=dil * (k // 2), mode=1, seg2=seg2, **kw)
+                         OC=conv_cin, KH=k, KW=k, stride=stride, dil=dil, pad=dil * (k // 2), mode=1, seg2=seg2, dtype=_cdt(dt), **kw)
 
         # ---- per-view adjoints of the x8 upsamples / gather of the stride-8 gradients
         d_cam_low, d_rvd = [], []
@@ -623,7 +677,7 @@ class Engine:
             if trainable("f9"):
                 g9 = torch.zeros(192, 195, device=dev, dtype=torch.float32)
                 L.conv_wgrad(S["feat"], dF, g9, N=N, IH=hdims[0][0], IW=hdims[0][1], IC=FEAT_LD, OH=hdims[0][0], OW=hdims[0][1], OC=192,
-                             KH=1, KW=1, IC_dw=195, seg2=seg(hdims, hdims))
+                             KH=1, KW=1, IC_dw=195, seg2=seg(hdims, hdims), dtype=_cdt(dt))
                 gv = self.grad_view("f9").reshape(192, 195)
                 gv[:, 3:67] += g9[:, 0:64]
                 gv[:, 67:195] += g9[:, 64:192]
@@ -645,7 +699,7 @@ class Engine:
         if trainable("fc_proj") or trainable("fc8"):
             off, _ = self.offsets["fc_proj"]
             L.conv_wgrad(S["fea"], d_head_rows, self.flat_g[off:off + 149 * 4096], N=N, IH=hdims[0][0], IW=hdims[0][1], IC=4096,
-                         OH=hdims[0][0], OW=hdims[0][1], OC=HEAD_LD, KH=1, KW=1, OC_dw=149, seg2=seg(hdims, hdims))
+                         OH=hdims[0][0], OW=hdims[0][1], OC=HEAD_LD, KH=1, KW=1, OC_dw=149, seg2=seg(hdims, hdims), dtype=_cdt(dt))
         s7, _ = P["bn"]["bn7"]
         D = E(M, 4096)
         dgrad(d_head_rows, "head", D, 4096, HEAD_LD, 1, 1, 1, hdims, hdims, epi=1, scale=s7,
@@ -712,6 +766,7 @@ class Engine:
                     dgrad(du1, name + ".conv_branch2a", Din, cin, c4, 1, stride, 1, din, dout, epi=1, scale=sa, mask=sv["t"], r_pre=tmp)
                 D = Din
                 block_done(name)
+        planes.clear()
         if wstream is not None:
             main.wait_stream(wstream)
             keep.clear()

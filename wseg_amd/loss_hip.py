@@ -181,7 +181,8 @@ def step(model, img1, img2, label20, bg_threshold=0.20, rng=None, rng_parity=Fal
     eng.ensure_flat(dev)
     eng.attach_grads()
     defer = os.environ.get("WSEG_DEFER_PACKS", "1") != "0"      # (0: A/B switch — packs and memset before the forward pass)
-    eng.ensure_packs(dev, L.BF16 if model.precision == "bf16" else L.F32, defer_wt=defer)
+    from .engine import DT_OF
+    eng.ensure_packs(dev, DT_OF[model.precision], defer_wt=defer)
     if zero_grads and not defer:
         eng.flat_g.zero_()
     acc = torch.zeros(8, device=dev, dtype=torch.float32)   # [cls1+cls2, (rvmin1+rvmin2)/2, er_sum, ecr, cross, cross2, intra]

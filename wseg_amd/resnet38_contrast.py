@@ -81,7 +81,7 @@ class Net(nn.Module):
         self.not_training = [self.conv1a, self.b2, self.b2_1, self.b2_2]
         self.normalize = Normalize()
         self.precision = precision or os.environ.get("WSEG_PRECISION", "bf16")
-        assert self.precision in ("bf16", "fp32")
+        assert self.precision in ("bf16", "fp32", "bf16x3")      # bf16x3: f32 storage, conv / wgrad products as split-bf16 (wseg_hip.h WSEG_F32X3)
 
     @property
     def _engine(self):
