@@ -13,7 +13,7 @@ lr = 1e-5
 opt = PolyOptimizer([{'params': groups[0], 'lr': lr, 'weight_decay': 5e-4}, {'params': groups[1], 'lr': 2*lr, 'weight_decay': 0},
                      {'params': groups[2], 'lr': 10*lr, 'weight_decay': 5e-4}, {'params': groups[3], 'lr': 20*lr, 'weight_decay': 0}], lr=lr, weight_decay=5e-4, max_step=5000)
 model.load_state_dict(synth.procedural_state_dict(0, device=dev)); model.cuda(); model.train()
-tr = Trainer(model, opt, 0.20, random.Random(0), False, "hip")
+tr = Trainer(model, opt, 0.20, random.Random(0), False)
 img = synth.synthetic_images(16, 448, 0, dev); lab = synth.synthetic_labels(16, 0, dev)
 for _ in range(3): tr.step(img, lab)
 torch.cuda.synchronize()

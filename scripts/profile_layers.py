@@ -7,14 +7,14 @@ from wseg_amd.optim import PolyOptimizer
 from wseg_amd.resnet38_contrast import Net
 from wseg_amd.train import Trainer
 dev = "cuda"
-model = Net(precision="bf16")
+model = Net(precision=sys.argv[1] if len(sys.argv) > 1 else "bf16")
 with contextlib.redirect_stdout(io.StringIO()):
     groups = model.get_parameter_groups()
 lr = 1e-5
 opt = PolyOptimizer([{'params': groups[0], 'lr': lr, 'weight_decay': 5e-4}, {'params': groups[1], 'lr': 2*lr, 'weight_decay': 0},
                      {'params': groups[2], 'lr': 10*lr, 'weight_decay': 5e-4}, {'params': groups[3], 'lr': 20*lr, 'weight_decay': 0}], lr=lr, weight_decay=5e-4, max_step=5000)
 model.load_state_dict(synth.procedural_state_dict(0, device=dev)); model.cuda(); model.train()
-tr = Trainer(model, opt, 0.20, random.Random(0), False, os.environ.get("WSEG_LOSS", "hip"))
+tr = Trainer(model, opt, 0.20, random.Random(0), False)
 img = synth.synthetic_images(16, 448, 0, dev); lab = synth.synthetic_labels(16, 0, dev)
 for _ in range(2): tr.step(img, lab)
 L.PROFILE, L.PROFILE_WGRAD = [], []
