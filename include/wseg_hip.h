@@ -271,6 +271,28 @@ typedef struct {
 int wseg_nce_records(const wseg_nce_view* views, int nviews, int P, void* stream);
 int wseg_nce_fused(const wseg_nce_view* views, int nviews, int P, float coef_cross, float coef_intra, float* sums /* [3], accumulated */, void* stream);
 
+/* ---- training augmentation on the device (contrast_train.py:64-75, tool/imutils.py:6-67, network/resnet38d.py:104-118): a batch of
+ * DECODED uint8 HWC images -> RandomResizeLong (Pillow's two-pass 8-bit bicubic, coefficient tables made by the host) -> horizontal flip ->
+ * ColorJitter ops in the drawn order (Pillow's ImageEnhance / HSV arithmetic) -> normalise (3 x 256 table) -> RandomCrop placement -> CHW f32.
+ * The host draws the random parameters (wseg_amd/augment.py, same draws in the same order as the host pipeline) and fills one
+ * descriptor per image; all pointers are device pointers; `tmp` / `img` are scratch of H*rw*3 and rh*rw*3 bytes. */
+typedef struct {
+  const uint8_t* src; int32_t H, W;                   /* decoded image [H][W][3] */
+  int32_t rh, rw;                                     /* size after RandomResizeLong */
+  const int32_t* xb; const int32_t* xk; int32_t xks;  /* horizontal pass: bounds [rw][2] = (first source column, count), coefficients [rw][xks] (22 fractional bits) */
+  const int32_t* yb; const int32_t* yk; int32_t yks;  /* vertical pass, over rh */
+  uint8_t* tmp; uint8_t* img;
+  int32_t flip;
+  int32_t op[4];                                      /* colour ops in execution order: 0 brightness, 1 contrast, 2 saturation, 3 hue, -1 none */
+  float factor[4];                                    /* enhancement factor of ops 0..2 */
+  int32_t hue_shift;                                  /* added to the uint8 hue (mod 256) */
+  int32_t cont_top, cont_left, img_top, img_left, ch, cw;   /* RandomCrop: [ch][cw] pixels from (img_top, img_left) land at (cont_top, cont_left) */
+  float* out;                                         /* [3][crop][crop] */
+} wseg_aug_desc;
+size_t wseg_sizeof_aug_desc(void);
+int wseg_augment_batch(const wseg_aug_desc* descs_dev, int n, int max_pixels /* largest H*rw or rh*rw of the batch */, const float* lut /* [3][256] */,
+                       int crop, unsigned long long* lum_sums /* scratch [n][4] */, void* stream);
+
 /* ---- fused SGD step (tool/torchutils.py:23-33 -> torch.optim.SGD.step) ------------------------
  * One pass over the flat buffers: d = g*grad_scale + wd*p; buf = first ? d : momentum*buf + d;
  * p -= lr*buf.  Segments [begin,end) carry the per-group lr / weight_decay (contrast_train.py:91-96).

@@ -6,7 +6,8 @@
 `--batch_size` keeps the reference's meaning — the GLOBAL batch (nn.DataParallel splits it over the GPUs, contrast_train.py:80-90,108):
 every rank takes batch_size / world images per step and max_step = (len(dataset) // batch_size) * max_epoches (:88).
 Additive flags only: --labels (path of cls_labels.npy/.npz), --synthetic N (N procedural images instead of
-VOC), --precision, --rng_parity, --seed (rank r seeds torch with seed + r: Dropout2d masks and hard-pixel keys differ per rank).  Logging keeps the reference's line format and its
+VOC), --precision, --rng_parity, --device_augment (the transform chain of :64-75 on the GPU, wseg_amd/augment.py: DataLoader workers only
+decode the JPEGs and draw the random parameters), --seed (rank r seeds torch with seed + r: Dropout2d masks and hard-pixel keys differ per rank).  Logging keeps the reference's line format and its
 `imps` definition (images, not views, per second; :413-420); tensorboardX is not available offline.
 """
 import argparse
@@ -48,6 +49,7 @@ def main(argv=None):
     parser.add_argument("--precision", default=None, choices=[None, "bf16", "fp32", "bf16x3"])
     parser.add_argument("--rng_parity", action="store_true")
     parser.add_argument("--seed", default=0, type=int)
+    parser.add_argument("--device_augment", action="store_true")
     args = parser.parse_args(argv)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -70,9 +72,19 @@ def main(argv=None):
     Net = getattr(importlib.import_module(args.network), 'Net')
     model = Net(precision=args.precision) if args.precision else Net()
 
+    aug = None
     if args.synthetic:
         n_img = args.synthetic
         loader = None
+    elif args.device_augment:
+        from . import augment as waug
+        ds = waug.VOC12ClsDatasetRaw(args.train_list, args.voc12_root, args.labels, args.crop_size)
+        n_img = len(ds)
+        sampler = torch.utils.data.distributed.DistributedSampler(ds, shuffle=True) if world > 1 else None
+        loader = torch.utils.data.DataLoader(ds, batch_size=local_batch, shuffle=sampler is None, sampler=sampler, collate_fn=waug.collate,
+                                             num_workers=args.num_workers, pin_memory=True, drop_last=True,
+                                             worker_init_fn=lambda wid: (np.random.seed(args.seed + 1 + wid + 1000 * rank), random.seed(args.seed + 1 + wid + 1000 * rank)))
+        aug = waug.DeviceAugment(dev, args.crop_size)
     else:
         ds = wdata.VOC12ClsDataset(args.train_list, args.voc12_root, args.labels, wdata.train_transform(model, args.crop_size))
         n_img = len(ds)
@@ -109,10 +121,14 @@ def main(argv=None):
         if loader is not None and world > 1:
             loader.sampler.set_epoch(ep)
         it = iter(loader) if loader is not None else None
+        if aug is not None:
+            it = aug.batches(it)                            # (decode workers -> device augmentation one batch ahead, on a side stream)
         for itn in range(steps_per_epoch):
             if it is None:
                 img = synth.synthetic_images(local_batch, args.crop_size, seed=(ep * steps_per_epoch + itn) * world + rank, device=dev)
                 lab = synth.synthetic_labels(local_batch, seed=(ep * steps_per_epoch + itn) * world + rank, device=dev)
+            elif aug is not None:
+                img, lab = next(it)
             else:
                 pack = next(it)
                 img, lab = pack[1].cuda(dev, non_blocking=True), pack[2].cuda(dev, non_blocking=True)
