@@ -268,7 +268,9 @@ typedef struct {
   float* rec;            /* [3][P] out (nce_records) */
   float* dF;             /* [P][128] out (nce_fused) */
 } wseg_nce_view;
-int wseg_nce_records(const wseg_nce_view* views, int nviews, int P, void* stream);
+/* nce_records, split_bf16 = 0: exact-f32 MFMA (the fp32 parity mode: the record's similarity is bit-identical to the one nce_fused uses);
+ * 1: split-bf16 products (hi.hi + lo.hi + hi.lo on the bf16 MFMA, 16-17 operand bits; the bf16 and bf16x3 modes — the similarity only RANKS pixels) */
+int wseg_nce_records(const wseg_nce_view* views, int nviews, int P, int split_bf16, void* stream);
 int wseg_nce_fused(const wseg_nce_view* views, int nviews, int P, float coef_cross, float coef_intra, float* sums /* [3], accumulated */, void* stream);
 
 /* ---- training augmentation on the device (contrast_train.py:64-75, tool/imutils.py:6-67, network/resnet38d.py:104-118): a batch of

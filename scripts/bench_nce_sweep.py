@@ -5,7 +5,7 @@ Bandwidth is ALGORITHMIC bytes / time, per launch, both views i
   nce_records  (forward half: similarities -> hard-pixel records)   P*(128*4 features + 4 label + 4 key)  read, P*12 written  = 532 B / pixel
   nce_fused    (similarities + 3 InfoNCE terms + gradient)          P*(128*4 + 4 + 4 + 4) read, P*128*4 dF written           = 1036 B / pixel
   (+ 2 x 21 x 128 x 4 B of prototypes per view, negligible)
-The unfused reference formulation (nce_sims + nce_loss_grad: normalised features and [P,21] similarity rows written to HBM and re-read)
+`records x3` is the record pass with split-bf16 products (the bf16 / bf16x3 precision modes); the plain columns use the exact-f32 MFMA.  The unfused reference formulation (nce_sims + nce_loss_grad: normalised features and [P,21] similarity rows written to HBM and re-read)
 is timed beside it and charged the SAME algorithmic bytes (1036 B / pixel for the pair), so the two columns compare like for like."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -19,7 +19,7 @@ def timeit(fn, iters):
     for _ in range(iters): fn()
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / iters * 1e3     # us
-print(f"{'P/view':>9s} | {'records us':>10s} {'GB/s':>8s} {'%8TB/s':>7s} | {'fused us':>9s} {'GB/s':>8s} {'%8TB/s':>7s} | {'unfused sims+grad us':>20s} {'GB/s':>8s} {'%8TB/s':>7s}")
+print(f"{'P/view':>9s} | {'records us':>10s} {'GB/s':>8s} {'%8TB/s':>7s} | {'fused us':>9s} {'GB/s':>8s} {'%8TB/s':>7s} | {'records x3 us':>13s} {'GB/s':>8s} {'%8TB/s':>7s} | {'unfused sims+grad us':>20s} {'GB/s':>8s} {'%8TB/s':>7s}")
 for lg in (12, 14, 16, 18, 20, 22):
     P = 1 << lg
     V = []
@@ -39,6 +39,8 @@ for lg in (12, 14, 16, 18, 20, 22):
             L.nce_sims(v["F"], v["p"], o["p"], v["fn"], v["nrm"], v["So"], v["St"], P)
             L.nce_loss_grad(v["fn"], v["nrm"], v["So"], v["St"], v["y"], o["y"], v["w"], v["p"], o["p"], v["dF"], sums, P, 0.1 / (2 * P), 0.05)
     t2 = timeit(unfused, it)
+    t3 = timeit(lambda: L.nce_records(rec_views, P, split_bf16=True), it)
     b0 = 2 * (P * 532 + 21 * 128 * 4)
     b1 = 2 * (P * 1036 + 2 * 21 * 128 * 4)
-    print(f"{P:9d} | {t0:10.2f} {b0/t0/1e3:8.1f} {b0/t0/1e3/8000*100:6.1f}% | {t1:9.2f} {b1/t1/1e3:8.1f} {b1/t1/1e3/8000*100:6.1f}% | {t2:20.2f} {b1/t2/1e3:8.1f} {b1/t2/1e3/8000*100:6.1f}%", flush=True)
+    print(f"{P:9d} | {t0:10.2f} {b0/t0/1e3:8.1f} {b0/t0/1e3/8000*100:6.1f}% | {t1:9.2f} {b1/t1/1e3:8.1f} {b1/t1/1e3/8000*100:6.1f}% | {t3:13.2f} {b0/t3/1e3:8.1f} {b0/t3/1e3/8000*100:6.1f}% | "
+          f"{t2:20.2f} {b1/t2/1e3:8.1f} {b1/t2/1e3/8000*100:6.1f}%", flush=True)

@@ -200,11 +200,12 @@ def test_prototype_exchange_two_ranks_on_one_gpu():
     np.testing.assert_allclose(p3.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("img_hw,crop,prec", [((96, 128), 128, "bf16"), ((448, 448), 448, "fp32")])
-def test_cli_plumbing_train_then_infer(tmp_path, monkeypatch, img_hw, crop, prec):
+@pytest.mark.parametrize("img_hw,crop,prec,dev_aug", [((96, 128), 128, "bf16", False), ((448, 448), 448, "fp32", False), ((375, 500), 448, "bf16x3", True)])
+def test_cli_plumbing_train_then_infer(tmp_path, monkeypatch, img_hw, crop, prec, dev_aug):
     """BASELINE.json config 1 on the GPU path: 4 synthetic VOC-format JPEGs, batch_size 2, 1 epoch -> contrast.pth ->
     contrast_infer writes <name>.npy / <name>.png in the reference's formats.  Second case: the config's stated size
-    (448 x 448 JPEGs, --crop_size 448, the reference's default) in the parity precision."""
+    (448 x 448 JPEGs, --crop_size 448, the reference's default) in the parity precision.  Third case: VOC-sized 375 x 500 JPEGs through the
+    device-side augmentation (--device_augment) in the split-bf16 mode."""
     import PIL.Image
     from wseg_amd import contrast_infer, contrast_train, synth
     root = tmp_path / "VOC2012"; (root / "JPEGImages").mkdir(parents=True)
@@ -218,7 +219,7 @@ def test_cli_plumbing_train_then_infer(tmp_path, monkeypatch, img_hw, crop, prec
     monkeypatch.chdir(tmp_path)
     contrast_train.main(["--weights", "procedural", "--batch_size", "2", "--max_epoches", "1", "--train_list", str(lst),
                          "--voc12_root", str(root), "--labels", str(tmp_path / "cls_labels.npy"), "--crop_size", str(crop),
-                         "--num_workers", "0", "--session_name", "t", "--lr", "1e-5", "--precision", prec])
+                         "--num_workers", "0", "--session_name", "t", "--lr", "1e-5", "--precision", prec] + (["--device_augment"] if dev_aug else []))
     ckpt = tmp_path / "result" / "t" / "contrast.pth"
     assert ckpt.exists()
     sd = torch.load(ckpt, weights_only=True)

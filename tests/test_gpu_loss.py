@@ -315,6 +315,12 @@ def test_fused_nce_matches_the_unfused_formulation(P):
         assert torch.isfinite(v["dF"]).all()
     assert torch.allclose(sums, ref_sums, rtol=2e-6, atol=0), (sums, ref_sums)
     assert float(ref_sums.abs().min()) > 0
+    # split-bf16 form of the record pass (bf16 / bf16x3 modes): labels and keys identical, similarities to 3e-6
+    rec3 = [torch.empty(3, P, device=dev) for _ in V]
+    L.nce_records([dict(F=v["F"], p_own=v["p"], y_own=v["y"], rkey=v["rkey"], rec=r) for v, r in zip(V, rec3)], P, split_bf16=True)
+    for v, r in zip(V, rec3):
+        assert torch.equal(r[0].view(torch.int32), v["rec_ref"][0].view(torch.int32)) and torch.equal(r[2], v["rec_ref"][2])
+        assert float((r[1] - v["rec_ref"][1]).abs().max()) <= 3e-6
     # the records feed the sort-based sampler through a leading dimension of 1 exactly as the [P,21] table did through 21
     w21, w1 = torch.empty(P, device=dev), torch.empty(P, device=dev)
     L.intra_weights(V[0]["y"], V[0]["So"], V[0]["rkey"], None, w21, P)

@@ -304,9 +304,9 @@ def _nce_views(views):
     return arr
 
 
-def nce_records(views, P):
+def nce_records(views, P, split_bf16=False):
     """views: list of dicts (F, p_own, y_own, rec[, rkey]) — one launch for all of them."""
-    _call("wseg_nce_records", _nce_views(views), len(views), P)
+    _call("wseg_nce_records", _nce_views(views), len(views), P, int(split_bf16))
 
 
 def nce_fused(views, P, coef_cross, coef_intra, sums):

@@ -860,15 +860,38 @@ struct NceArgs { NceView v[2]; int nviews, P; float coef_cross, coef_intra; floa
 
 // similarities of 16 pixels (rows grp16*16 ..) to the 42 prototypes held in pb; returns acc[t][r] = S[pixel 4g+r][class t*16+col]
 // already divided by the pixel's norm, and the lane's own row norm in `nr` (row = lane & 15)
+// Feature tile of 16 pixels (8 KB) through LDS (the record pass): lane (col, g) needs 16 B at channel 16b + 4g of pixel `col` — 64-B pieces of 16
+// different rows per load instruction when fetched straight into registers.  Here 8 LDS-DMA instructions fetch two WHOLE rows each (1 KB contiguous
+// per wave instruction) and cost no registers, so a wave keeps TWO tiles (16 KB) in flight; the 16-B chunks are XOR-swizzled on the source side
+// (chunk ^ row in the low 4 bits) so that the fragment reads of one chunk index from 16 rows fall into 16 different bank groups.  The tile belongs
+// to ONE wave: no barrier, only that wave's vmcnt.  Measured at P = 2^22 per view: 2.92 -> 3.25 TB/s (exact f32), 2.83 -> 3.84 TB/s (split-bf16);
+// with one tile in flight the staging alone changed nothing — these kernels are bound by bytes in flight per CU (latency), not by the load shape.
+__device__ __forceinline__ void nce_tile_dma(const float* __restrict__ F, int P, int grp16, int lane, char* tile) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int r = 2 * i + (lane >> 5), pc = lane & 31;           // row inside the tile, physical 16-B chunk inside the row
+    const int lc = (pc & 16) | ((pc ^ r) & 15);                  // logical chunk stored there
+    glds16(F + (size_t)min(grp16 * 16 + r, P - 1) * 128 + lc * 4, tile + i * 1024);
+  }
+}
+__device__ __forceinline__ void nce_frags_global(const float* __restrict__ F, int P, int grp16, int col, int g, f32x4 (&a)[8]) {
+  const float* fr = F + (size_t)min(grp16 * 16 + col, P - 1) * 128 + 4 * g;
+#pragma unroll
+  for (int b = 0; b < 8; ++b) a[b] = *reinterpret_cast<const f32x4*>(fr + b * 16);
+}
+__device__ __forceinline__ void nce_frags_lds(const char* tile, int col, int g, f32x4 (&a)[8]) {
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    const int lc = 4 * b + g;
+    a[b] = *reinterpret_cast<const f32x4*>(tile + col * 512 + (((lc & 16) | ((lc ^ col) & 15)) << 4));
+  }
+}
+
 template <int NT = 3>   // NT = 2: only the first 32 classes (the record pass needs the own-view prototypes only)
-__device__ __forceinline__ void nce_sims16(const float* __restrict__ F, int P, int grp16, int col, int g, const f32x4 (&pb)[3][8],
-                                           f32x4 (&acc)[3], float& nr) {
-  const int row = grp16 * 16 + col;
-  const float* fr = F + (size_t)min(row, P - 1) * 128 + 4 * g;
-  f32x4 a[8];
+__device__ __forceinline__ void nce_sims16(const f32x4 (&a)[8], int col, int g, const f32x4 (&pb)[3][8], f32x4 (&acc)[3], float& nr) {
   float ss = 0.f;
 #pragma unroll
-  for (int b = 0; b < 8; ++b) { a[b] = *reinterpret_cast<const f32x4*>(fr + b * 16); ss += a[b][0] * a[b][0] + a[b][1] * a[b][1] + a[b][2] * a[b][2] + a[b][3] * a[b][3]; }
+  for (int b = 0; b < 8; ++b) ss += a[b][0] * a[b][0] + a[b][1] * a[b][1] + a[b][2] * a[b][2] + a[b][3] * a[b][3];
   ss += __shfl_xor(ss, 16, 64); ss += __shfl_xor(ss, 32, 64);
   nr = sqrtf(ss);
   const float inv = 1.f / fmaxf(nr, 1e-12f);
@@ -898,22 +921,94 @@ __device__ __forceinline__ void nce_load_protos(const float* __restrict__ p_own,
   }
 }
 
+// ---- split-bf16 form of the same contraction (the record pass in the bf16 and bf16x3 precision modes; the fp32 mode and the fused loss kernel
+// keep the exact-f32 MFMA above — a split-bf16 form of the fused kernel was measured: 2.97 vs 2.79 TB/s at P = 2^22, equal at the real shape, at the
+// price of register spills; not kept).
+// Operands x = hi + lo (bf16 each), product lo.hi + hi.lo + hi.hi on v_mfma_f32_16x16x32_bf16: 36 MFMAs of 16 cycles per 16 pixels instead of
+// 96 of 32 — the exact-f32 MFMA (1/16 of the bf16 rate) is what bounds the f32 kernels, not HBM.  Lane (col, g) holds channels
+// 32c + 4g + e and 32c + 16 + 4g + e (e = 0..3) of chunk c: exactly its two 16-B feature loads 2c and 2c + 1, same map for both operands.
+struct NceProtosX3 { bf16x8 hi[3][4], lo[3][4]; };
+__device__ __forceinline__ void nce_load_protos_x3(const float* __restrict__ p_own, const float* __restrict__ p_oth, int col, int g, NceProtosX3& pp) {
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int cc = t * 16 + col;
+    const float* src = cc < 21 ? p_own + cc * 128 : (cc < 42 && p_oth ? p_oth + (cc - 21) * 128 : nullptr);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      f32x4 q0 = (f32x4){0.f, 0.f, 0.f, 0.f}, q1 = q0;
+      if (src) { q0 = *reinterpret_cast<const f32x4*>(src + 32 * c + 4 * g); q1 = *reinterpret_cast<const f32x4*>(src + 32 * c + 16 + 4 * g); }
+      split_bf16x8(q0, q1, pp.hi[t][c], pp.lo[t][c]);
+    }
+  }
+}
+template <int NT = 3>
+__device__ __forceinline__ void nce_sims16_x3(const f32x4 (&a)[8], int col, int g, const NceProtosX3& pp, f32x4 (&acc)[3], float& nr) {
+  float ss = 0.f;
+#pragma unroll
+  for (int b = 0; b < 8; ++b) ss += a[b][0] * a[b][0] + a[b][1] * a[b][1] + a[b][2] * a[b][2] + a[b][3] * a[b][3];
+  ss += __shfl_xor(ss, 16, 64); ss += __shfl_xor(ss, 32, 64);
+  nr = sqrtf(ss);
+  const float inv = 1.f / fmaxf(nr, 1e-12f);
+#pragma unroll
+  for (int t = 0; t < 3; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    bf16x8 ah, al;
+    split_bf16x8(a[2 * c], a[2 * c + 1], ah, al);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, pp.hi[t][c], acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, pp.lo[t][c], acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, pp.hi[t][c], acc[t], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float ir = __shfl(inv, 4 * g + r, 64);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) acc[t][r] *= ir;
+  }
+}
+
+template <bool X3>
 __global__ __launch_bounds__(256) void nce_records_kernel(const NceArgs a) {
+  constexpr int TL = 2;                                      // 16-pixel tiles per wave iteration: 16 KB of features in flight per wave (4: one workgroup per CU, measured slower)
+  __shared__ __attribute__((aligned(16))) char tiles[4][TL * 8192];
   const int lane = threadIdx.x & 63, col = lane & 15, g = lane >> 4;
-  const int P = a.P, ngrp = (P + 15) >> 4;
-  {
-    for (int gid = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); gid < a.nviews * ngrp; gid += gridDim.x * 4) {   // both views share the grid
-      const NceView& v = a.v[gid >= ngrp ? 1 : 0];
-      const int grp = gid >= ngrp ? gid - ngrp : gid;
-      f32x4 pb[3][8];
-      nce_load_protos(v.p_own, nullptr, col, g, pb);
-      f32x4 acc[3]; float nr;
-      nce_sims16<2>(v.F, P, grp, col, g, pb, acc, nr);
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  char* tile = tiles[wv];
+  const int P = a.P, ngrp = (P + 15) >> 4, npair = (ngrp + TL - 1) / TL;
+  f32x4 pb[X3 ? 1 : 3][8];
+  NceProtosX3 pp;
+  int cur_v = -1;
+  for (int gid = blockIdx.x * 4 + wv; gid < a.nviews * npair; gid += gridDim.x * 4) {      // both views share the grid
+    const int vi = gid >= npair ? 1 : 0;
+    const NceView& v = a.v[vi];
+    const int grp0 = (gid - vi * npair) * TL;
+#pragma unroll
+    for (int t = 0; t < TL; ++t) nce_tile_dma(v.F, P, min(grp0 + t, ngrp - 1), lane, tile + t * 8192);
+    int yv[TL][4];                                           // the labels of this lane's four pixels per tile, requested beside the tiles
+#pragma unroll
+    for (int t = 0; t < TL; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) yv[t][r] = v.y_own[min((grp0 + t) * 16 + 4 * g + r, P - 1)];
+    if (vi != cur_v) {                                       // prototypes of the view (wave-uniform branch; at most twice per wave)
+      cur_v = vi;
+      if constexpr (X3) nce_load_protos_x3(v.p_own, nullptr, col, g, pp); else nce_load_protos(v.p_own, nullptr, col, g, pb);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int t = 0; t < TL; ++t) {
+      const int grp = grp0 + t;
+      if (grp >= ngrp) break;
+      f32x4 acc[3], fa[8]; float nr;
+      nce_frags_lds(tile + t * 8192, col, g, fa);
+      if constexpr (X3) nce_sims16_x3<2>(fa, col, g, pp, acc, nr); else nce_sims16<2>(fa, col, g, pb, acc, nr);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int p = grp * 16 + 4 * g + r;
         if (p < P) {
-          const int c = v.y_own[p];                          // lane (col, g) holds classes col and 16 + col of pixel 4g + r
+          const int c = yv[t][r];                            // lane (col, g) holds classes col and 16 + col of pixel 4g + r
           if (c == col) { v.rec[p] = __int_as_float(c); v.rec[P + p] = acc[0][r]; if (v.rkey) v.rec[2 * P + p] = v.rkey[p]; }
           else if (c == 16 + col) { v.rec[p] = __int_as_float(c); v.rec[P + p] = acc[1][r]; if (v.rkey) v.rec[2 * P + p] = v.rkey[p]; }
         }
@@ -941,8 +1036,9 @@ __global__ __launch_bounds__(256, 2) void nce_fused_kernel(const NceArgs a) {
         nce_load_protos(po, pt, col, g, pb);
 #pragma unroll 1
         for (int sub = 0; sub < 4; ++sub) {
-          f32x4 acc[3]; float nr;
-          nce_sims16(v.F, P, grp * 4 + sub, col, g, pb, acc, nr);
+          f32x4 acc[3], fa[8]; float nr;
+          nce_frags_global(v.F, P, grp * 4 + sub, col, g, fa);
+          nce_sims16(fa, col, g, pb, acc, nr);
 #pragma unroll
           for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -1026,9 +1122,10 @@ __global__ __launch_bounds__(256, 2) void nce_fused_kernel(const NceArgs a) {
           const float inv_s = 1.f / fmaxf(nr, 1e-12f);
           f32x4 f[8];
           float dot = 0.f;
+          nce_frags_global(v.F, P, grp * 4 + sub, col, g, f);          // (second touch of the wave's own 32 KB of features: cache-resident)
 #pragma unroll
-          for (int mt = 0; mt < 8; ++mt) {                   // (second touch of the wave's own 32 KB of features: cache-resident)
-            f[mt] = *reinterpret_cast<const f32x4*>(v.F + (size_t)pc * 128 + mt * 16 + 4 * g) * inv_s;
+          for (int mt = 0; mt < 8; ++mt) {
+            f[mt] = f[mt] * inv_s;
             dot += acc[mt][0] * f[mt][0] + acc[mt][1] * f[mt][1] + acc[mt][2] * f[mt][2] + acc[mt][3] * f[mt][3];
           }
           dot += __shfl_xor(dot, 16, 64); dot += __shfl_xor(dot, 32, 64);
@@ -1248,10 +1345,12 @@ static int nce_args(const wseg_nce_view* views, int nviews, int P, NceArgs& a, b
   }
   return 0;
 }
-extern "C" int wseg_nce_records(const wseg_nce_view* views, int nviews, int P, void* stream) {
+extern "C" int wseg_nce_records(const wseg_nce_view* views, int nviews, int P, int split_bf16, void* stream) {
   NceArgs a{};
   if (int rc = nce_args(views, nviews, P, a, false)) return rc;
-  hipLaunchKernelGGL(nce_records_kernel, dim3(std::min(2048, (nviews * ((P + 15) / 16) + 3) / 4)), dim3(256), 0, ST, a);
+  const dim3 grid(std::min(2048, (nviews * ((P + 31) / 32) + 3) / 4));
+  if (split_bf16) hipLaunchKernelGGL(nce_records_kernel<true>, grid, dim3(256), 0, ST, a);
+  else hipLaunchKernelGGL(nce_records_kernel<false>, grid, dim3(256), 0, ST, a);
   WSEG_LAUNCH_CHECK();
   return 0;
 }

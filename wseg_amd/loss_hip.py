@@ -232,6 +232,8 @@ def step(model, img1, img2, label20, bg_threshold=0.20, rng=None, rng_parity=Fal
     #  RNG-parity path, which replays the reference's host random stream)
     global_intra = distributed or (not rng_parity and os.environ.get("WSEG_INTRA_GLOBAL", "1") == "1")
     rank = dist.get_rank() if distributed else 0
+    # record pass (similarities that only RANK pixels): exact-f32 MFMA in fp32 mode, split-bf16 products in the bf16 / bf16x3 modes
+    nce_x3 = model.precision != "fp32" and os.environ.get("WSEG_NCE_X3", "1") != "0"
     cst = side[1]
     cst.wait_stream(main)
     with torch.cuda.stream(cst):
@@ -243,7 +245,7 @@ def step(model, img1, img2, label20, bg_threshold=0.20, rng=None, rng_parity=Fal
         rec = _f32(2, 3, P, dev=dev)
         for vi, v in enumerate(views):
             v.rkey = _random_keys(P, rank, vi, dev) if global_intra else None
-        L.nce_records([dict(F=v.F, p_own=v.protos, y_own=v.y, rkey=v.rkey, rec=rec[vi]) for vi, v in enumerate(views)], P)
+        L.nce_records([dict(F=v.F, p_own=v.protos, y_own=v.y, rkey=v.rkey, rec=rec[vi]) for vi, v in enumerate(views)], P, split_bf16=nce_x3)
         grec = rec
     # ---- ER + ECR on the 128x128 maps (both directions of the ECR top-k in ONE 2N-row selection)
     npix = 128 * 128
