@@ -121,10 +121,13 @@ def intra_view_nce(f, pseudo, protos, rng, record=None):
     return loss / C
 
 
-def step_loss(out1, out2, label20, bg_threshold=0.20, rng=None, extras=None):
+def step_loss(out1, out2, label20, bg_threshold=0.20, rng=None, extras=None, inject=None):
     """contrast_train.py:138-395 given the two forward 4-tuples.
     out_v = (cam_v, cam_rv_v, f_proj_v, cam_rv_v_down); label20 float [N,20].
-    Returns dict of the 8 logged scalars (tensors; 'loss' carries the graph)."""
+    Returns dict of the 8 logged scalars (tensors; 'loss' carries the graph).
+    inject: optional {protos1, protos2, pseudo1, pseudo2} — ANOTHER implementation's discrete selections (its per-class top-32 prototypes, its
+    pseudo-labels) used in place of this one's: a near-tie at the top-32 boundary resolved differently moves a prototype by ~4e-3 and the NCE terms
+    by ~1e-4 at P = 512, without any arithmetic difference (tests/test_gpu_loss.py)."""
     rng = rng if rng is not None else _random.Random(0)
     cam1, cam_rv1, f_proj1, cam_rv1_down = out1
     cam2, cam_rv2, f_proj2, cam_rv2_down = out2
@@ -162,6 +165,10 @@ def step_loss(out1, out2, label20, bg_threshold=0.20, rng=None, extras=None):
     pseudo1, protos1, ncam1 = pseudo_labels_and_prototypes(cam_rv1_down, f_proj1, label, bg_threshold)
     pseudo2, protos2, ncam2 = pseudo_labels_and_prototypes(cam_rv2_down, f_proj2, label, bg_threshold)
 
+    if inject is not None:
+        pseudo1, pseudo2 = inject.get("pseudo1", pseudo1), inject.get("pseudo2", pseudo2)
+        protos1, protos2 = inject.get("protos1", protos1), inject.get("protos2", protos2)
+
     def rows(fp):
         n_f, c_f, h_f, w_f = fp.shape
         return F.normalize(fp.permute(0, 2, 3, 1).reshape(n_f * h_f * w_f, c_f), dim=-1)
@@ -186,7 +193,7 @@ def step_loss(out1, out2, label20, bg_threshold=0.20, rng=None, extras=None):
                 loss_cross_nce=loss_cross_nce, loss_cross_nce2=loss_cross_nce2)
 
 
-def train_step(img1, label20, sd, masks1=None, masks2=None, bg_threshold=0.20, rng=None, extras=None, gates1=None, gates2=None):
+def train_step(img1, label20, sd, masks1=None, masks2=None, bg_threshold=0.20, rng=None, extras=None, gates1=None, gates2=None, inject=None):
     """One loop body, contrast_train.py:130-395: second view, two forwards, the loss.  gates1 / gates2: optional injected ReLU
     decisions per view (oracle/net.py `_relu`)."""
     img2 = F.interpolate(img1, size=(128, 128), mode="bilinear", align_corners=True)
@@ -194,4 +201,4 @@ def train_step(img1, label20, sd, masks1=None, masks2=None, bg_threshold=0.20, r
     out2 = onet.net_forward(img2, sd, masks2, gates=gates2)
     if extras is not None:
         extras.update(out1=out1, out2=out2)
-    return step_loss(out1, out2, label20, bg_threshold, rng, extras)
+    return step_loss(out1, out2, label20, bg_threshold, rng, extras, inject)

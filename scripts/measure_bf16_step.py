@@ -15,7 +15,7 @@ prec = sys.argv[1] if len(sys.argv) > 1 else "bf16"
 G = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 sd = synth.procedural_state_dict(0)
 out = {}
-for name in ("step_S160_N2", "step_S128_N3", "step_edge_S64_N3"):
+for name in ("step_S160_N2", "step_S128_N3", "step_edge_S64_N3", "step_S448_N2", "step_S448_N2_b"):
     g = np.load(os.path.join(G, name + ".npz"))
     n, size, seed, py_seed = int(g["n"]), int(g["size"]), int(g["seed"]), int(g["py_seed"])
     model, opt, tr = _trainer(sd, prec, "hip", n, seed, py_seed)

@@ -158,6 +158,65 @@ def test_gradients_under_the_hip_paths_relu_decisions(golden_dir, proc_sd, name,
     print(f"{name} [{prec}]: {flipped} of {len(GRAD_KEYS)} keys differ from the reference fixture by more than 2e-3 (none from the gate-injected oracle)")
 
 
+# Full resolution (BASELINE config 2: 448 x 448, 56 x 56 maps), two draws, fixtures from the reference.  At this resolution the per-class top-32 of
+# 512 contrast pixels (contrast_train.py:202-203) regularly holds a near-tie at its boundary: in both fixtures the smallest relative gap between the
+# 32nd and the 33rd value of some class is 1.6e-5, inside the ~1e-5 by which the PCM-refined CAM of two exact-f32 implementations differs (the CAM
+# gate of resnet38_contrast.py:46-48 is discontinuous).  One membership swap moves that class's prototype by ~4e-3 and the NCE terms by ~1e-4 at
+# P = 512 — measured on step_S448_N2: every pseudo-label equal, 41 of 42 prototypes equal to 6e-6, class 15 of view 1 off by 4.4e-3, loss_nce off by
+# 1.12e-4 (scripts/diag_s448.py).  So: (a) against the reference fixture the non-NCE scalars are held to 1e-4 and the NCE terms to 4e-4;
+# (b) the arithmetic is held to 1e-4 on ALL 8 scalars by the selection-injected oracle: the CPU oracle re-run with the HIP path's own prototypes
+# and pseudo-labels in place of its own.
+S448_NCE_BAR = 4e-4
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("name", ["step_S448_N2", "step_S448_N2_b"])
+def test_full_resolution_step_against_reference_fixture(golden_dir, proc_sd, name, prec):
+    from oracle import loss as oloss
+    from wseg_amd import synth
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    n, size, seed, py_seed = int(g["n"]), int(g["size"]), int(g["seed"]), int(g["py_seed"])
+    model, opt, tr = _trainer(proc_sd, prec, "hip", n, seed, py_seed)
+    model._engine.capture_ctx = True
+    img, lab = synth.synthetic_images(n, size, seed), synth.synthetic_labels(n, seed)
+    got = tr.step(img.cuda(), lab.cuda())
+    v1, v2 = model._engine.last_loss_views
+    model._engine.capture_ctx, model._engine.last_ctx, model._engine.last_loss_views = False, None, None
+    nce = ("loss", "loss_nce", "loss_intra_nce", "loss_cross_nce", "loss_cross_nce2")
+    for k in SCALARS:
+        ref = float(g["s/" + k])
+        bar = S448_NCE_BAR if k in nce else 1e-4
+        assert abs(float(got[k]) - ref) <= bar * max(1.0, abs(ref)), (k, float(got[k]), ref)
+    for v, key in ((v1, "pseudo1"), (v2, "pseudo2")):
+        assert float((v.y.cpu().numpy() != g[key].astype(np.int32)).mean()) <= 1 / 256, key            # (pseudo-labels: at most a near-tie pixel or two)
+    swaps = sum(int((np.abs(v.protos.cpu().numpy() - g[key]).max(axis=1) > 1e-4).sum()) for v, key in ((v1, "protos1"), (v2, "protos2")))
+    assert swaps <= 3, swaps
+    inject = dict(protos1=v1.protos.cpu(), protos2=v2.protos.cpu(), pseudo1=v1.y.cpu().long(), pseudo2=v2.y.cpu().long())
+    with torch.no_grad():
+        ref = oloss.train_step(img, lab, dict(proc_sd), synth.synthetic_dropout_masks(n, seed * 2), synth.synthetic_dropout_masks(n, seed * 2 + 1),
+                               0.20, random.Random(py_seed), inject=inject)
+    for k in SCALARS:
+        assert abs(float(got[k]) - float(ref[k])) <= 1e-4 * max(1.0, abs(float(ref[k]))), ("selection-injected", k, float(got[k]), float(ref[k]))
+    print(f"{name} [{prec}]: {swaps} prototype(s) differ from the reference by a top-32 near-tie; all 8 scalars within 1e-4 of the selection-injected oracle")
+
+
+def test_bf16_full_resolution_step(golden_dir, proc_sd):
+    """Throughput mode at the real resolution against the reference's fixtures: measured relative deviations (profiles/r02_bf16_deviation.json) loss 1.7e-2,
+    cls 1e-4, er 1e-3, ecr 1.4e-3, nce 4.4e-2, intra 8.5e-2, cross 1.7e-3, cross2 6.5e-2 — the NCE terms move through prototype / pseudo-label
+    selections (discrete), which bf16 forward noise changes; bars = 2x measured."""
+    from wseg_amd import synth
+    bars = {"loss": 3.4e-2, "loss_cls": 4.2e-3, "loss_er": 1.5e-2, "loss_ecr": 2.7e-2, "loss_nce": 9e-2, "loss_intra_nce": 1.7e-1,
+            "loss_cross_nce": 2.3e-2, "loss_cross_nce2": 1.3e-1}
+    for name in ("step_S448_N2", "step_S448_N2_b"):
+        g = np.load(os.path.join(golden_dir, name + ".npz"))
+        n, size, seed, py_seed = int(g["n"]), int(g["size"]), int(g["seed"]), int(g["py_seed"])
+        model, opt, tr = _trainer(proc_sd, "bf16", "hip", n, seed, py_seed)
+        got = tr.step(synth.synthetic_images(n, size, seed).cuda(), synth.synthetic_labels(n, seed).cuda())
+        for k in SCALARS:
+            ref = float(g["s/" + k])
+            assert abs(float(got[k]) - ref) <= bars[k] * abs(ref), (name, k, float(got[k]), ref)
+
+
 def _multistep(proc_sd, g, prec, loss_impl="hip"):
     """The 3-step fixture's protocol on the HIP path; returns ([per-step scalar dict], {key: relative error of the weight
     DELTA w_after - w_before on the fixture's 4096-sample slice})."""

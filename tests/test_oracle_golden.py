@@ -36,7 +36,7 @@ def test_net_forward_eval(golden_dir, proc_sd, name):
     assert (cam_rv.argmax(1).numpy() == g["cam_rv_argmax"]).mean() > 0.9999
 
 
-@pytest.mark.parametrize("name", ["step_S160_N2", "step_S128_N3", "step_edge_S64_N3"])
+@pytest.mark.parametrize("name", ["step_S160_N2", "step_S128_N3", "step_edge_S64_N3", "step_S448_N2", "step_S448_N2_b"])
 def test_train_step_loss_and_grads(golden_dir, proc_sd, name):
     g = _load(golden_dir, name)
     n, size, seed, py_seed = int(g["n"]), int(g["size"]), int(g["seed"]), int(g["py_seed"])

@@ -295,6 +295,8 @@ def step(model, img1, img2, label20, bg_threshold=0.20, rng=None, rng_parity=Fal
         L.head_grad_fused(v.dF, v.d_cam_low, v.head, d_head[v.off:], HEAD_LD, N, v.h, v.w, 16, 16)
     main.wait_stream(aux)
     eng.run_backward(ctx, [(None, v.d_rvd, None, None) for v in views], d_head_rows=d_head)
+    if eng.capture_ctx:                                     # tests: pseudo-labels, prototypes, hard-pixel weights of both views
+        eng.last_loss_views = views
     loss_cls = acc[0] * 0.5 + acc[1]
     loss_er = acc[2] * er_coef
     loss_ecr = acc[3]
