@@ -336,11 +336,12 @@ def test_bf16_three_steps_against_reference_fixture(golden_dir, proc_sd):
             assert abs(scal[s_][k] - ref) <= BF16_SCALAR_BAR[k] * abs(ref), (s_, k, scal[s_][k], ref)
 
 
-@pytest.mark.parametrize("P", [4096, 1000])
+@pytest.mark.parametrize("P", [4096, 1000, 300007])
 def test_fused_nce_matches_the_unfused_formulation(P):
     """csrc/loss.hip nce_records + nce_fused (the product path: both views in one launch, nothing but records / dF written)
     against the unfused reference formulation nce_sims -> intra_pack -> nce_loss_grad on the same inputs: the records and dF
-    bit for bit (same MFMA arithmetic), the three loss sums up to the order of the float atomics.  P = 1000: row tails."""
+    bit for bit (same MFMA arithmetic), the three loss sums up to the order of the float atomics.  P = 1000: row tails;
+    P = 300007: every wave of the record pass walks 4-5 tiles (its two-tiles-in-flight pipeline in steady state, odd and even trip counts)."""
     from wseg_amd import _lib as L
     dev = "cuda"
     g = torch.Generator().manual_seed(P)
@@ -381,6 +382,7 @@ def test_fused_nce_matches_the_unfused_formulation(P):
         assert torch.equal(r[0].view(torch.int32), v["rec_ref"][0].view(torch.int32)) and torch.equal(r[2], v["rec_ref"][2])
         assert float((r[1] - v["rec_ref"][1]).abs().max()) <= 3e-6
     # the records feed the sort-based sampler through a leading dimension of 1 exactly as the [P,21] table did through 21
+    if P > 8192: return                              # (the single-rank sampler sorts one view in LDS: P <= 8192)
     w21, w1 = torch.empty(P, device=dev), torch.empty(P, device=dev)
     L.intra_weights(V[0]["y"], V[0]["So"], V[0]["rkey"], None, w21, P)
     L.intra_weights(V[0]["y"], V[0]["rec"][1], V[0]["rkey"], None, w1, P, ld_s=1)

@@ -98,6 +98,12 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
                                    (void __attribute__((address_space(3)))*)lds_wave_base, 16, 0, 0);
 }
 
+// async 4-byte global -> LDS copy (LDS destination = wave-uniform base + lane*4)
+__device__ __forceinline__ void glds4(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)gsrc,
+                                   (void __attribute__((address_space(3)))*)lds_wave_base, 4, 0, 0);
+}
+
 // XCD-aware bijective remap of a 1-D block id: blocks that share an XCD (id % 8) get a
 // contiguous run of logical tiles, so neighbouring tiles share that XCD's L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

@@ -970,50 +970,83 @@ __device__ __forceinline__ void nce_sims16_x3(const f32x4 (&a)[8], int col, int 
   }
 }
 
+// One wave walks the 16-pixel tiles id = first + k * (waves in the grid) of BOTH views (view 0's tiles, then view 1's) with TWO tiles always in
+// flight: tile k + 2 is requested into the buffer tile k was read from as soon as its fragments are in registers, so the wave never drains its
+// queue (the unpipelined form — request two tiles, wait for both, compute both — had nothing in flight while it computed).  The record of pixel j
+// of a tile is gathered into lane j (8 ds_bpermute from the lane that holds the pixel's own class), so every tile issues the SAME number of memory
+// operations (8 LDS-DMA + label + key loads, 2-3 stores) and the only wait is one counted vmcnt.
 template <bool X3>
 __global__ __launch_bounds__(256) void nce_records_kernel(const NceArgs a) {
-  constexpr int TL = 2;                                      // 16-pixel tiles per wave iteration: 16 KB of features in flight per wave (4: one workgroup per CU, measured slower)
-  __shared__ __attribute__((aligned(16))) char tiles[4][TL * 8192];
+  // per wave: two 8-KB feature tiles, then per buffer 64 labels | 64 keys (lanes 0..15 are the tile's pixels).  ONE __shared__ object: beside a
+  // second one the compiler puts a vmcnt(0) in front of every ds_read while LDS-DMA is in flight
+  __shared__ __attribute__((aligned(16))) char lds[4][2 * 8192 + 2 * 512];
   const int lane = threadIdx.x & 63, col = lane & 15, g = lane >> 4;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  char* tile = tiles[wv];
-  const int P = a.P, ngrp = (P + 15) >> 4, npair = (ngrp + TL - 1) / TL;
+  char* tile = lds[wv];
+  char* side = lds[wv] + 2 * 8192;
+  const int P = a.P, ngrp = (P + 15) >> 4, total = a.nviews * ngrp, W = gridDim.x * 4;
+  const int first = blockIdx.x * 4 + wv;
+  if (first >= total) return;
+  const bool has_key = a.v[0].rkey != nullptr;               // (both views or none: checked on the host)
   f32x4 pb[X3 ? 1 : 3][8];
   NceProtosX3 pp;
-  int cur_v = -1;
-  for (int gid = blockIdx.x * 4 + wv; gid < a.nviews * npair; gid += gridDim.x * 4) {      // both views share the grid
-    const int vi = gid >= npair ? 1 : 0;
+  // (labels and keys travel through LDS as well: a register that is the destination of a load in flight across the loop edge makes the compiler
+  //  copy it at the latch behind a vmcnt(0))
+  auto request = [&](int id, int buf) {                       // tile `id` (clamped: a dummy request keeps the operation count fixed) -> buffer buf
+    id = min(id, total - 1);
+    const int vi = id >= ngrp ? 1 : 0;
     const NceView& v = a.v[vi];
-    const int grp0 = (gid - vi * npair) * TL;
-#pragma unroll
-    for (int t = 0; t < TL; ++t) nce_tile_dma(v.F, P, min(grp0 + t, ngrp - 1), lane, tile + t * 8192);
-    int yv[TL][4];                                           // the labels of this lane's four pixels per tile, requested beside the tiles
-#pragma unroll
-    for (int t = 0; t < TL; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) yv[t][r] = v.y_own[min((grp0 + t) * 16 + 4 * g + r, P - 1)];
-    if (vi != cur_v) {                                       // prototypes of the view (wave-uniform branch; at most twice per wave)
+    const int grp = id - vi * ngrp;
+    nce_tile_dma(v.F, P, grp, lane, tile + buf * 8192);
+    const int p = min(grp * 16 + col, P - 1);
+    glds4(v.y_own + p, side + buf * 512);
+    if (has_key) glds4(v.rkey + p, side + buf * 512 + 256);
+  };
+  int cur_v = -1;
+  auto body = [&](int id, int buf) {                          // (buf is a literal at both call sites)
+    const int vi = id >= ngrp ? 1 : 0, grp = id - vi * ngrp;
+    const NceView& v = a.v[vi];
+    if (vi != cur_v) {                                        // prototypes of the view (wave-uniform branch; at most twice per wave)
       cur_v = vi;
-      if constexpr (X3) nce_load_protos_x3(v.p_own, nullptr, col, g, pp); else nce_load_protos(v.p_own, nullptr, col, g, pb);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if constexpr (X3) nce_load_protos_x3(v.p_own, nullptr, col, g, pp);
+      else {
+        nce_load_protos(v.p_own, nullptr, col, g, pb);
 #pragma unroll
-    for (int t = 0; t < TL; ++t) {
-      const int grp = grp0 + t;
-      if (grp >= ngrp) break;
-      f32x4 acc[3], fa[8]; float nr;
-      nce_frags_lds(tile + t * 8192, col, g, fa);
-      if constexpr (X3) nce_sims16_x3<2>(fa, col, g, pp, acc, nr); else nce_sims16<2>(fa, col, g, pb, acc, nr);
+        for (int t = 0; t < 2; ++t)                           // a USE inside the branch: the compiler waits for these loads here, not (with a
+#pragma unroll                                                //  vmcnt(0), which would drain the tiles in flight) at their first use in the loop
+          for (int b = 0; b < 8; ++b) asm volatile("" : "+v"(pb[t][b]));
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (has_key) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");   // younger than tile k: stores(k-2) 3, tile k+1 10, stores(k-1) 3
+    else asm volatile("s_waitcnt vmcnt(11)" ::: "memory");                  // (2, 9, 2)
+    f32x4 acc[3], fa[8]; float nr;
+    nce_frags_lds(tile + buf * 8192, col, g, fa);
+    const int yc = *reinterpret_cast<const int*>(side + buf * 512 + col * 4);
+    const float kc = *reinterpret_cast<const float*>(side + buf * 512 + 256 + col * 4);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    request(id + 2 * W, buf);
+    if constexpr (X3) nce_sims16_x3<2>(fa, col, g, pp, acc, nr); else nce_sims16<2>(fa, col, g, pb, acc, nr);
+    // lane j < 16 <- similarity of pixel j to its class c: held by lane (c & 15) + 16 * (j >> 2) in acc[c >> 4][j & 3]
+    const int src = (yc & 15) + 16 * (col >> 2);
+    float sim = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int p = grp * 16 + 4 * g + r;
-        if (p < P) {
-          const int c = yv[t][r];                            // lane (col, g) holds classes col and 16 + col of pixel 4g + r
-          if (c == col) { v.rec[p] = __int_as_float(c); v.rec[P + p] = acc[0][r]; if (v.rkey) v.rec[2 * P + p] = v.rkey[p]; }
-          else if (c == 16 + col) { v.rec[p] = __int_as_float(c); v.rec[P + p] = acc[1][r]; if (v.rkey) v.rec[2 * P + p] = v.rkey[p]; }
-        }
+        const float x = __shfl(acc[t][r], src, 64);
+        if ((yc >> 4) == t && (col & 3) == r) sim = x;
       }
+    const int p = grp * 16 + col;
+    if (g == 0 && p < P) {
+      v.rec[p] = __int_as_float(yc); v.rec[P + p] = sim;
+      if (has_key) v.rec[2 * P + p] = kc;
     }
+  };
+  request(first, 0);
+  request(first + W, 1);
+  for (int id = first; id < total; id += 2 * W) {
+    body(id, 0);
+    if (id + W < total) body(id + W, 1);
   }
 }
 
@@ -1028,16 +1061,19 @@ __global__ __launch_bounds__(256, 2) void nce_fused_kernel(const NceArgs a) {
     for (int gid = blockIdx.x * 4 + wv; gid < a.nviews * ngrp; gid += gridDim.x * 4) {   // both views share the grid
       const NceView& v = a.v[gid >= ngrp ? 1 : 0];
       const int grp = gid >= ngrp ? gid - ngrp : gid;
-      // ---------------- similarities of 4 x 16 pixels -> the wave's slab
+      // ---------------- similarities of 4 x 16 pixels -> the wave's slab.  The features of sub-tile s + 1 are requested before the 96 MFMAs of
+      // sub-tile s (two register sets), the labels / weights of phase A before everything: no load of this phase is waited for right after its issue
+      const int pA = min(grp * 64 + lane, P - 1);
+      const int yo = v.y_own[pA], yt = v.y_oth[pA];
+      const float wA = v.w_intra[pA];
       {
         const float *po = v.p_own, *pt = v.p_oth;            // (opaque copies: keeps the compiler from hoisting the 96 prototype registers
         asm volatile("" : "+s"(po), "+s"(pt));               //  of this phase and the 88 of phase B over the whole loop — they never overlap)
-        f32x4 pb[3][8];
+        f32x4 pb[3][8], f0[8], f1[8];
+        nce_frags_global(v.F, P, grp * 4, col, g, f0);
         nce_load_protos(po, pt, col, g, pb);
-#pragma unroll 1
-        for (int sub = 0; sub < 4; ++sub) {
-          f32x4 acc[3], fa[8]; float nr;
-          nce_frags_global(v.F, P, grp * 4 + sub, col, g, fa);
+        auto sims_of = [&](int sub, const f32x4 (&fa)[8]) {
+          f32x4 acc[3]; float nr;
           nce_sims16(fa, col, g, pb, acc, nr);
 #pragma unroll
           for (int r = 0; r < 4; ++r)
@@ -1047,7 +1083,11 @@ __global__ __launch_bounds__(256, 2) void nce_fused_kernel(const NceArgs a) {
               if (cc < 42) slab[wv][sub * 16 + 4 * g + r][cc] = acc[t][r];
             }
           if (g == 0) slab[wv][sub * 16 + col][44] = nr;
-        }
+        };
+        nce_frags_global(v.F, P, grp * 4 + 1, col, g, f1); __builtin_amdgcn_sched_barrier(0); sims_of(0, f0);
+        nce_frags_global(v.F, P, grp * 4 + 2, col, g, f0); __builtin_amdgcn_sched_barrier(0); sims_of(1, f1);
+        nce_frags_global(v.F, P, grp * 4 + 3, col, g, f1); __builtin_amdgcn_sched_barrier(0); sims_of(2, f0);
+        sims_of(3, f1);
       }
       __builtin_amdgcn_wave_barrier();
       // ---------------- phase A, lane = pixel: the three InfoNCE terms and d(loss)/d(similarity)
@@ -1058,8 +1098,7 @@ __global__ __launch_bounds__(256, 2) void nce_fused_kernel(const NceArgs a) {
         float so[21], st[21];
 #pragma unroll
         for (int c = 0; c < 21; ++c) { so[c] = slab[wv][lane][c]; st[c] = slab[wv][lane][21 + c]; }
-        const int yo = v.y_own[pc], yt = v.y_oth[pc];
-        const float wi = ok ? v.w_intra[pc] : 0.f;
+        const float wi = ok ? wA : 0.f;
         float eo[21], et[21], sum_o = 0.f, sum_t = 0.f, e_yo_t = 0.f, e_yt_o = 0.f, e_yo_o = 0.f;
 #pragma unroll
         for (int c = 0; c < 21; ++c) {
@@ -1097,7 +1136,9 @@ __global__ __launch_bounds__(256, 2) void nce_fused_kernel(const NceArgs a) {
       {
         const float *po = v.p_own, *pt = v.p_oth;
         asm volatile("" : "+s"(po), "+s"(pt));
-        float pa[8][11];                                     // A operand: [P_own|P_oth]^T[ch = mt*16+col][class 4kk+g]
+        f32x4 f0[8], f1[8];
+        nce_frags_global(v.F, P, grp * 4, col, g, f0);       // (second touch of the wave's own 32 KB of features: cache-resident; sub-tile s + 1 is
+        float pa[8][11];                                     //  requested before the 88 MFMAs of sub-tile s)    A operand: [P_own|P_oth]^T[ch = mt*16+col][class 4kk+g]
 #pragma unroll
         for (int kk = 0; kk < 11; ++kk) {
           const int cc = 4 * kk + g;
@@ -1105,8 +1146,7 @@ __global__ __launch_bounds__(256, 2) void nce_fused_kernel(const NceArgs a) {
 #pragma unroll
           for (int mt = 0; mt < 8; ++mt) pa[mt][kk] = src ? src[mt * 16 + col] : 0.f;
         }
-#pragma unroll 1
-        for (int sub = 0; sub < 4; ++sub) {
+        auto grad_of = [&](int sub, f32x4 (&f)[8]) {
           const int p = grp * 64 + sub * 16 + col;           // B / C column = pixel
           f32x4 acc[8];
 #pragma unroll
@@ -1117,12 +1157,9 @@ __global__ __launch_bounds__(256, 2) void nce_fused_kernel(const NceArgs a) {
 #pragma unroll
             for (int mt = 0; mt < 8; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[mt][kk], bv, acc[mt], 0, 0, 0);
           }
-          const int pc = min(p, P - 1);
           const float nr = slab[wv][sub * 16 + col][44];
           const float inv_s = 1.f / fmaxf(nr, 1e-12f);
-          f32x4 f[8];
           float dot = 0.f;
-          nce_frags_global(v.F, P, grp * 4 + sub, col, g, f);          // (second touch of the wave's own 32 KB of features: cache-resident)
 #pragma unroll
           for (int mt = 0; mt < 8; ++mt) {
             f[mt] = f[mt] * inv_s;
@@ -1135,7 +1172,11 @@ __global__ __launch_bounds__(256, 2) void nce_fused_kernel(const NceArgs a) {
             for (int mt = 0; mt < 8; ++mt)
               *reinterpret_cast<f32x4*>(v.dF + (size_t)p * 128 + mt * 16 + 4 * g) = (acc[mt] - f[mt] * dot) * inv;
           }
-        }
+        };
+        nce_frags_global(v.F, P, grp * 4 + 1, col, g, f1); __builtin_amdgcn_sched_barrier(0); grad_of(0, f0);
+        nce_frags_global(v.F, P, grp * 4 + 2, col, g, f0); __builtin_amdgcn_sched_barrier(0); grad_of(1, f1);
+        nce_frags_global(v.F, P, grp * 4 + 3, col, g, f1); __builtin_amdgcn_sched_barrier(0); grad_of(2, f0);
+        grad_of(3, f1);
       }
       __builtin_amdgcn_wave_barrier();
     }
@@ -1340,7 +1381,7 @@ static int nce_args(const wseg_nce_view* views, int nviews, int P, NceArgs& a, b
     const wseg_nce_view& w = views[i];
     WSEG_CHECK(w.F && w.p_own && w.y_own, "nce: view %d: F, p_own, y_own are required", i);
     if (need_grad) WSEG_CHECK(w.p_oth && w.y_oth && w.w_intra && w.dF, "nce_fused: view %d: p_oth, y_oth, w_intra, dF are required", i);
-    else WSEG_CHECK(w.rec, "nce_records: view %d: rec is required", i);
+    else WSEG_CHECK(w.rec && (w.rkey != nullptr) == (views[0].rkey != nullptr), "nce_records: view %d: rec is required; rkey for every view or none", i);
     a.v[i] = NceView{w.F, w.p_own, w.p_oth, w.y_own, w.y_oth, w.w_intra, w.rkey, w.rec, w.dF};
   }
   return 0;
@@ -1348,7 +1389,7 @@ static int nce_args(const wseg_nce_view* views, int nviews, int P, NceArgs& a, b
 extern "C" int wseg_nce_records(const wseg_nce_view* views, int nviews, int P, int split_bf16, void* stream) {
   NceArgs a{};
   if (int rc = nce_args(views, nviews, P, a, false)) return rc;
-  const dim3 grid(std::min(2048, (nviews * ((P + 31) / 32) + 3) / 4));
+  const dim3 grid(std::min(2048, (nviews * ((P + 15) / 16) + 3) / 4));
   if (split_bf16) hipLaunchKernelGGL(nce_records_kernel<true>, grid, dim3(256), 0, ST, a);
   else hipLaunchKernelGGL(nce_records_kernel<false>, grid, dim3(256), 0, ST, a);
   WSEG_LAUNCH_CHECK();
