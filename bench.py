@@ -75,13 +75,18 @@ def _spawn_ranks(a):
     return subprocess.run(cmd, env=env).returncode          # rank 0's JSON line goes to the inherited stdout
 
 
-def timed_steps(trainer, img, lab, steps, warmup, barrier):
-    for _ in range(warmup):
-        trainer.step(img, lab)
+def timed_steps(trainer, batches, steps, warmup, barrier, lookahead=True):
+    """batches: two (images, labels) pairs used alternately; step i is told the images of step i + 1 (as a prefetching loader would),
+    so the frozen prefix of the next forward pass runs inside the current step's loss phase."""
+    def one(i):
+        img, lab = batches[i % 2]
+        return trainer.step(img, lab, next_img1=batches[(i + 1) % 2][0] if lookahead else None)
+    for i in range(warmup):
+        one(i)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        losses = trainer.step(img, lab)
+    for i in range(warmup, warmup + steps):
+        losses = one(i)
     barrier()
     return time.perf_counter() - t0, losses
 
@@ -120,6 +125,8 @@ def main():
     ap.add_argument("--parity-precision", default=os.environ.get("WSEG_PARITY_PRECISION", "fp32,bf16x3"),
                     help="comma list of the parity-grade modes to time: fp32 (exact-f32 MFMA), bf16x3 (f32 storage, split-bf16 products)")
     ap.add_argument("--event-stride", type=int, default=5, help="bracket every k-th conv launch with HIP events (rotating)")
+    ap.add_argument("--no-lookahead", action="store_true", help="do not tell step i the images of step i + 1 (A/B switch: the frozen prefix of the "
+                                                                "next forward pass then runs in front of it instead of inside the loss phase)")
     ap.add_argument("--seed", type=int, default=0, help="base seed: rank r draws its images / labels / dropout masks / keys from seed + r")
     ap.add_argument("--lr", type=float, default=1e-5,
                     help="base lr; the reference's 0.01 makes the RANDOM procedural weights diverge within 2 steps "
@@ -159,16 +166,22 @@ def main():
     from wseg_amd import synth
 
     model, trainer = build_trainer(a.precision, a.lr, dev, a.seed + rank)
-    img = synth.synthetic_images(a.batch, a.size, seed=a.seed + rank, device=dev)
-    lab = synth.synthetic_labels(a.batch, seed=a.seed + rank, device=dev)
+    # two synthetic batches used alternately: step i is given the images of step i + 1, as a prefetching data loader would
+    batches = [(synth.synthetic_images(a.batch, a.size, seed=a.seed + rank + 7919 * j, device=dev),
+                synth.synthetic_labels(a.batch, seed=a.seed + rank + 7919 * j, device=dev)) for j in range(2)]
+    look = not a.no_lookahead
+
+    def one_step(i):
+        img, lab = batches[i % 2]
+        return trainer.step(img, lab, next_img1=batches[(i + 1) % 2][0] if look else None)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        trainer.step(img, lab)
+    for i in range(a.warmup):
+        one_step(i)
     # HIP events around the conv_igemm launches, live in the timed region, on the launch stream.  An event pair costs
     # ~10 us of stream time, so launch i of step s is bracketed only when (i + s) % stride == 0: every launch index
     # is sampled steps/stride times while the timed region slows by ~0.2 ms/step instead of ~1 ms.
@@ -178,7 +191,7 @@ def main():
     t0 = time.perf_counter()
     for it in range(a.steps):
         L.profile_begin_step(it)
-        losses = trainer.step(img, lab)
+        losses = one_step(a.warmup + it)
     barrier()
     dt = time.perf_counter() - t0
     prof, L.PROFILE = L.PROFILE, None
@@ -221,7 +234,8 @@ def main():
                 "dtype": {"bf16": "bf16", "fp32": "f32", "bf16x3": "bf16x3 (hi/lo split, f32 accumulate)"}[a.precision], "data": "synthetic",
                 "config": {"workload": f"ResNet-38 contrast, synthetic VOC {a.size}x{a.size}, B={a.batch}/GPU, "
                                        f"procedural weights, dropout on, fused HIP loss",
-                           "global_batch": a.batch * world, "parallelism": f"dp{world}", "seed": a.seed},
+                           "global_batch": a.batch * world, "parallelism": f"dp{world}", "seed": a.seed,
+                           "input": "two synthetic batches alternate" + ("; step i is given the images of step i+1 (prefetching-loader lookahead)" if look else "")},
                 "loss": float(losses["loss"]), "roofline": roof}
     # ---- the parity mode's throughput (the mode the 1e-4 / argmax-exact evidence is for), same workload, rank 0 at N=1 only
     if rank == 0 and world == 1 and a.parity_steps > 0 and a.precision == "bf16":
@@ -230,7 +244,7 @@ def main():
         line["parity_mode"] = []
         for pprec in a.parity_precision.split(","):
             pmodel, ptrainer = build_trainer(pprec, a.lr, dev, a.seed + rank)
-            pdt, plosses = timed_steps(ptrainer, img, lab, a.parity_steps, 1, barrier)
+            pdt, plosses = timed_steps(ptrainer, batches, a.parity_steps, 1, barrier, look)
             pms = pdt / a.parity_steps * 1e3
             ppeak = PEAKS[pprec]
             line["parity_mode"].append({"precision": pprec, "ms_per_step": round(pms, 2), "value": round(a.batch * a.parity_steps / pdt, 2),

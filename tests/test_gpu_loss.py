@@ -478,6 +478,49 @@ def test_full_size_step_properties(proc_sd):
     assert float((eng.flat_w - w0).abs().max()) > 0
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_lookahead_prefix_changes_nothing(proc_sd, prec):
+    """Trainer.step(img, lab, next_img1=...) computes the frozen part of the NEXT forward pass (conv1a, b2*) on a side stream inside this step's loss
+    phase.  Four steps over different batches with and without it: the 8 scalars of every step agree to the order of the float atomics in the loss sums
+    and the fc8 weights after the last step to 2e-3 of their total update (the weight-gradient kernels add split-K partials with f32 atomics, so two
+    runs of the SAME schedule differ by as much).  Step 3 is announced one tensor and given another (the
+    announced prefix must be dropped), step 4 gets a tensor that was modified in place after it was announced."""
+    from wseg_amd import synth
+    n, size, seed = 2, 160, 41
+    imgs = [synth.synthetic_images(n, size, seed + j).cuda() for j in range(5)]
+    labs = [synth.synthetic_labels(n, seed + j).cuda() for j in range(5)]
+    runs = []
+    for look in (False, True):
+        model, opt, tr = _trainer(proc_sd, prec, "hip", n, seed, 4, lr=3e-6)
+        model.set_dropout_masks(None)
+        tr.rng_parity = False
+        os.environ["WSEG_INTRA_KEY_SEED"] = "9"
+        torch.manual_seed(17)
+        try:
+            x3 = imgs[3].clone()
+            plan = [(imgs[0], imgs[1]), (imgs[1], imgs[4]), (imgs[2], x3), (x3, None)]     # (step 2 -> 3: announced imgs[4], given imgs[2])
+            out = []
+            for j, (img, nxt) in enumerate(plan):
+                if j == 3:
+                    x3.mul_(0.5)                                                         # modified after it was announced
+                got = tr.step(img, labs[j], next_img1=nxt if look else None)
+                out.append({k: float(v) for k, v in got.items()})
+        finally:
+            del os.environ["WSEG_INTRA_KEY_SEED"]
+        runs.append((out, model._engine.flat_w.clone()))
+    (a, wa), (b, wb) = runs
+    w0 = torch.cat([proc_sd[nm + ".weight"].reshape(-1) for nm in ("fc8",)]).cuda()
+    o8, c8 = model._engine.offsets["fc8"]
+    wa, wb = wa[o8:o8 + c8], wb[o8:o8 + c8]
+    for j, (x, y) in enumerate(zip(a, b)):
+        for k in SCALARS:
+            if k in ("loss", "loss_nce", "loss_intra_nce", "loss_cross_nce", "loss_cross_nce2", "loss_cls", "loss_er", "loss_ecr"):
+                # (step 0: float atomics in the loss sums only; later steps also carry the atomics noise of the weight gradients through the update)
+                assert abs(x[k] - y[k]) <= (2e-6 if j == 0 else 5e-5) * max(1.0, abs(x[k])), (j, k, x[k], y[k])
+    upd = float((wa - w0).abs().max())
+    assert upd > 0 and float((wa - wb).abs().max()) <= 2e-3 * upd, (upd, float((wa - wb).abs().max()))
+
+
 def test_packs_follow_the_weights_bf16(proc_sd):
     """After optimizer steps every derived weight buffer of the bf16 path — the cast mirror, the transposed dgrad packs (made on
     a side stream during the loss phase) and the K-concatenated packs of the two-source launches — equals what the CURRENT master

@@ -30,6 +30,8 @@ BLOCKS = [
 ]
 
 FROZEN_BLOCKS = ("b2", "b2_1", "b2_2")          # resnet38_contrast.py:29 (+ conv1a)
+N_FROZEN_BLOCKS = len(FROZEN_BLOCKS)            # they are the first blocks: the forward pass up to here depends on no trainable weight
+assert tuple(b[0] for b in BLOCKS[:N_FROZEN_BLOCKS]) == FROZEN_BLOCKS
 HEAD_CONVS = OrderedDict([                       # resnet38_contrast.py:15-20
     ("fc8",     (21,  4096)),
     ("fc_proj", (128, 4096)),

@@ -123,16 +123,25 @@ def main(argv=None):
         it = iter(loader) if loader is not None else None
         if aug is not None:
             it = aug.batches(it)                            # (decode workers -> device augmentation one batch ahead, on a side stream)
-        for itn in range(steps_per_epoch):
+        def fetch(itn):
+            if itn >= steps_per_epoch:
+                return None
             if it is None:
-                img = synth.synthetic_images(local_batch, args.crop_size, seed=(ep * steps_per_epoch + itn) * world + rank, device=dev)
-                lab = synth.synthetic_labels(local_batch, seed=(ep * steps_per_epoch + itn) * world + rank, device=dev)
-            elif aug is not None:
-                img, lab = next(it)
-            else:
-                pack = next(it)
-                img, lab = pack[1].cuda(dev, non_blocking=True), pack[2].cuda(dev, non_blocking=True)
-            losses = trainer.step(img, lab)
+                sd = (ep * steps_per_epoch + itn) * world + rank
+                return synth.synthetic_images(local_batch, args.crop_size, seed=sd, device=dev), synth.synthetic_labels(local_batch, seed=sd, device=dev)
+            if aug is not None:
+                return next(it)
+            pack = next(it)
+            return pack[1].cuda(dev, non_blocking=True), pack[2].cuda(dev, non_blocking=True)
+
+        cur = fetch(0)
+        for itn in range(steps_per_epoch):
+            # one batch ahead: the step is told the NEXT images, whose weight-independent prefix (conv1a, the frozen b2 blocks) it computes inside
+            # its own loss phase (Trainer.step next_img1)
+            nxt = fetch(itn + 1)
+            img, lab = cur
+            losses = trainer.step(img, lab, next_img1=nxt[0] if nxt is not None else None)
+            cur = nxt
             cnt += 1
             for k in KEYS:                                  # device-side accumulation: no per-step host sync
                 sums[k] = sums[k] + losses[k]

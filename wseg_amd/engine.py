@@ -395,21 +395,16 @@ class Engine:
         outs, _ = self.run_forward([x], save=False, lowres=lowres)
         return outs[0]
 
-    def run_forward(self, xs, save, lowres=False):
-        """xs: list of one or two image batches (same N).  Two views are BATCHED: every activation is one row
-        matrix [rows(view 1) ++ rows(view 2)][C] and every conv / wgrad is ONE launch over both row segments
-        (the 128x128 view alone cannot fill the chip).  Returns ([per-view output tuple], saved context)."""
+    def _run_blocks(self, xs, state, first, last, save, S, bm_hint=0):
+        """Blocks arch.BLOCKS[first:last] (first == 0: conv1a first) over the batched views.  state: the dict an earlier call returned."""
         net = self.net
         V = len(xs)
-        assert V in (1, 2)
         dev = xs[0].device
         dt = DT_OF[net.precision]
         tdt = L.TORCH_DTYPE[dt]
         P = self.ensure_packs(dev, dt)
         N = xs[0].shape[0]
-        assert all(x.shape[0] == N for x in xs)
-        masks = self._masks(N, V, dev)
-        S = {"masks": masks, "dims": {}, "N": N, "V": V, "dt": dt, "xs": xs, "lowres": lowres}
+        masks = S["masks"] if S is not None else None
 
         def rows_of(dims):
             return sum(N * h * w for (h, w) in dims)
@@ -427,20 +422,26 @@ class Engine:
         def conv(inp, wname, out, out2, cin, cout, k, stride, dil, din, dout, **kw):
             seg2 = (din[1][0], din[1][1], dout[1][0], dout[1][1]) if V == 2 else None
             L.conv_igemm(inp, P["w"][wname], out, out2, N=N, IH=din[0][0], IW=din[0][1], IC=cin, OH=dout[0][0], OW=dout[0][1],
-                         OC=cout, KH=k, KW=k, stride=stride, dil=dil, pad=dil * (k // 2), seg2=seg2, dtype=_cdt(dt), **kw)
+                         OC=cout, KH=k, KW=k, stride=stride, dil=dil, pad=dil * (k // 2), seg2=seg2, dtype=_cdt(dt), bm_hint=bm_hint, **kw)
 
         def next_bn(i):
             if i + 1 < len(arch.BLOCKS):
                 return P["bn"][arch.BLOCKS[i + 1][0] + ".bn_branch2a"], None
             return P["bn"]["bn7"], (masks["dropout7"] if masks else None)
 
-        dims = [(x.shape[2], x.shape[3]) for x in xs]
-        sc, sh = P["bn"]["b2.bn_branch2a"]
-        t = E(rows_of(dims), 64)
-        for x, off, (H, W) in zip(xs, offs_of(dims), dims):
-            L.stem_conv_kc(x, P["w"]["conv1a_kc"], sc, sh, None, t[off:], N, H, W, L.F32 if dt == L.F32X3 else dt)
-        xraw = None
-        for i, b in enumerate(arch.BLOCKS):
+        sdims = {}
+        conv4 = conv5 = None
+        if first == 0:
+            dims = [(x.shape[2], x.shape[3]) for x in xs]
+            sc, sh = P["bn"]["b2.bn_branch2a"]
+            t = E(rows_of(dims), 64)
+            for x, off, (H, W) in zip(xs, offs_of(dims), dims):
+                L.stem_conv_kc(x, P["w"]["conv1a_kc"], sc, sh, None, t[off:], N, H, W, L.F32 if dt == L.F32X3 else dt)
+            xraw = None
+        else:
+            t, xraw, dims = state["t"], state["xraw"], state["dims"]
+        for i in range(first, last):
+            b = arch.BLOCKS[i]
             name, kind, cin, mid, cout, stride, fd, d, p = b
             same = arch.block_same_shape(b)
             (nsc, nsh), ndrop = next_bn(i)
@@ -485,12 +486,62 @@ class Engine:
                     conv(v2, name + ".conv_branch2b2", xn, tn, c2, cout, 1, 1, 1, odims, odims, r_post=b1, scale=nsc, shift=nsh, drop=ndrop)
                 if save:
                     S[name] = dict(t=t, v1=v1, v2=v2)
-            S["dims"][name] = (dims, odims)
+            sdims[name] = (dims, odims)
+            if S is not None:
+                S["dims"][name] = (dims, odims)
             if name == "b5":
                 conv4 = t
             if name == "b6":
                 conv5 = t
             t, xraw, dims = tn, xn, odims
+        return dict(t=t, xraw=xraw, dims=dims, conv4=conv4, conv5=conv5, sdims=sdims, N=N, V=V, dt=dt)
+
+    def run_prefix(self, xs, bm_hint=0):
+        """The part of the forward pass that depends on no trainable weight: conv1a and the blocks Net.train() freezes (b2, b2_1, b2_2;
+        resnet38_contrast.py:86-95 `not_training`), for one or two batched views.  Returns what run_forward continues from.  Because it depends only on the
+        IMAGES, the fused step runs it for the NEXT batch on a side stream inside the loss phase of the current step (loss_hip.step `next_imgs`)."""
+        return self._run_blocks(xs, None, 0, arch.N_FROZEN_BLOCKS, False, None, bm_hint=bm_hint)
+
+    def run_forward(self, xs, save, lowres=False, prefix=None):
+        """xs: list of one or two image batches (same N).  Two views are BATCHED: every activation is one row
+        matrix [rows(view 1) ++ rows(view 2)][C] and every conv / wgrad is ONE launch over both row segments
+        (the 128x128 view alone cannot fill the chip).  Returns ([per-view output tuple], saved context).
+        prefix: the result of run_prefix(xs) when the caller has already computed it."""
+        net = self.net
+        V = len(xs)
+        assert V in (1, 2)
+        dev = xs[0].device
+        dt = DT_OF[net.precision]
+        tdt = L.TORCH_DTYPE[dt]
+        P = self.ensure_packs(dev, dt)
+        N = xs[0].shape[0]
+        assert all(x.shape[0] == N for x in xs)
+        masks = self._masks(N, V, dev)
+        S = {"masks": masks, "dims": {}, "N": N, "V": V, "dt": dt, "xs": xs, "lowres": lowres}
+        if prefix is None:
+            prefix = self._run_blocks(xs, None, 0, arch.N_FROZEN_BLOCKS, False, None)
+        assert prefix["N"] == N and prefix["V"] == V and prefix["dt"] == dt, "run_forward: the prefix was computed for another batch shape / precision"
+        S["dims"].update(prefix["sdims"])
+        st = self._run_blocks(xs, prefix, arch.N_FROZEN_BLOCKS, len(arch.BLOCKS), save, S)
+        t, dims, conv4, conv5 = st["t"], st["dims"], st["conv4"], st["conv5"]
+
+        def rows_of(dims):
+            return sum(N * h * w for (h, w) in dims)
+
+        def offs_of(dims):
+            o, out = 0, []
+            for (h, w) in dims:
+                out.append(o)
+                o += N * h * w
+            return out
+
+        def E(m, c):
+            return torch.empty((m, c), device=dev, dtype=tdt)
+
+        def conv(inp, wname, out, out2, cin, cout, k, stride, dil, din, dout, **kw):
+            seg2 = (din[1][0], din[1][1], dout[1][0], dout[1][1]) if V == 2 else None
+            L.conv_igemm(inp, P["w"][wname], out, out2, N=N, IH=din[0][0], IW=din[0][1], IC=cin, OH=dout[0][0], OW=dout[0][1],
+                         OC=cout, KH=k, KW=k, stride=stride, dil=dil, pad=dil * (k // 2), seg2=seg2, dtype=_cdt(dt), **kw)
 
         fea = t                                               # relu(bn7(x)) * dropout7   [M,4096]
         M = rows_of(dims)

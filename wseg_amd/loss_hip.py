@@ -25,7 +25,31 @@ _TIE_CACHE = {}
 def _side_streams(eng, dev):
     st = getattr(eng, "_side_streams", None)
     if st is None or st[0].device != dev:
-        st = eng._side_streams = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
+        pr = int(os.environ.get("WSEG_SIDE_PRIO", "0"))
+        st = eng._side_streams = (torch.cuda.Stream(dev, priority=pr), torch.cuda.Stream(dev, priority=pr))
+    return st
+
+
+def _prefix_stream(eng, dev):
+    """Stream of the next batch's frozen prefix (step(lookahead=...)).  WSEG_PREFIX_CUS=n < 256: a CU-masked stream (hipExtStreamCreateWithCUMask,
+    the first n mask bits set; the mask bits go round-robin over the 8 XCDs, so every XCD keeps (256 - n) / 8 CUs free): the prefix tiles occupy whole
+    CUs (all registers, 160 KiB of LDS), and the loss phase's small dependent kernels otherwise wait for a tile to end before each launch."""
+    st = getattr(eng, "_prefix_stream", None)
+    if st is None or st.device != dev:
+        ncu = int(os.environ.get("WSEG_PREFIX_CUS", "256"))
+        if ncu >= 256:
+            st = torch.cuda.Stream(dev)
+        else:
+            import ctypes as C
+            hip = C.CDLL("libamdhip64.so")
+            words = (C.c_uint32 * 8)(*[(((1 << max(0, min(32, ncu - 32 * i))) - 1) & 0xFFFFFFFF) for i in range(8)])
+            h = C.c_void_p()
+            with torch.cuda.device(dev):
+                rc = hip.hipExtStreamCreateWithCUMask(C.byref(h), C.c_uint32(8), words)
+            if rc != 0:
+                raise RuntimeError(f"hipExtStreamCreateWithCUMask failed ({rc})")
+            st = torch.cuda.ExternalStream(h.value, device=dev)
+        eng._prefix_stream = st
     return st
 
 
@@ -168,10 +192,13 @@ def _rand_flags(y_dev, rng, P):
     return flags.to(y_dev.device)
 
 
-def step(model, img1, img2, label20, bg_threshold=0.20, rng=None, rng_parity=False, bg_topk_idx=None, zero_grads=False):
+def step(model, img1, img2, label20, bg_threshold=0.20, rng=None, rng_parity=False, bg_topk_idx=None, zero_grads=False, prefix=None, lookahead=None):
     """Forward both views, all losses, backward into the engine's flat gradient buffer (accumulating; zero_grads=True clears
     the buffer first — on a side stream during the loss phase, where it costs nothing).  Returns the 8 logged scalars
-    (device tensors)."""
+    (device tensors).
+    prefix: Engine.run_prefix([img1, img2]) when an earlier call has computed it.  lookahead: {"img1": the NEXT batch's images}; this call adds
+    "img2" and "prefix" for them: the frozen part of the next forward pass (conv1a, b2*: 2.2 ms of conv work that depends on no trainable weight)
+    runs on its own stream between this step's forward and backward passes, where ~2 ms of small loss kernels leave the chip mostly idle."""
     eng = model._engine
     dev = img1.device
     N = img1.shape[0]
@@ -193,8 +220,19 @@ def step(model, img1, img2, label20, bg_threshold=0.20, rng=None, rng_parity=Fal
     side = _side_streams(eng, dev) if use_streams else (main, main)
     # Both views go through the network in ONE batched pass (two row segments per launch); the per-view map
     # losses then run on their own HIP streams.
-    outs, ctx = eng.run_forward([img1, img2], save=True, lowres=True)
+    outs, ctx = eng.run_forward([img1, img2], save=True, lowres=True, prefix=prefix)
     fork = main.record_event()
+    pst = None
+    if lookahead is not None:
+        from .train import second_view
+        pst = _prefix_stream(eng, dev)
+        pst.wait_event(fork)
+        with torch.cuda.stream(pst):
+            n1 = lookahead["img1"]
+            n2 = second_view(n1, img2.shape[-1])
+            lookahead["img2"], lookahead["prefix"] = n2, eng.run_prefix([n1, n2], bm_hint=int(os.environ.get("WSEG_PREFIX_TILE", "0")))
+        for t_ in (n2, lookahead["prefix"]["t"]):           # allocated on the prefix stream, consumed on the caller's in the next step
+            t_.record_stream(main)
     # Backward-only preparation — the transposed weight packs (420 MB of traffic) and the gradient memset (420 MB) — on a third
     # stream behind the forward pass: it runs while the loss phase's small kernels leave the chip's bandwidth idle.
     aux = _aux_stream(eng, dev) if use_streams else main
@@ -294,6 +332,8 @@ def step(model, img1, img2, label20, bg_threshold=0.20, rng=None, rng_parity=Fal
     for v in views:
         L.head_grad_fused(v.dF, v.d_cam_low, v.head, d_head[v.off:], HEAD_LD, N, v.h, v.w, 16, 16)
     main.wait_stream(aux)
+    if pst is not None:
+        main.wait_stream(pst)                               # (the heavy backward launches must not share the chip with the prefix tiles)
     eng.run_backward(ctx, [(None, v.d_rvd, None, None) for v in views], d_head_rows=d_head)
     if eng.capture_ctx:                                     # tests: pseudo-labels, prototypes, hard-pixel weights of both views
         eng.last_loss_views = views

@@ -58,15 +58,28 @@ class Trainer:
             lo, hi = buckets[name]
             self._pending.append(dist.all_reduce(eng.flat_g[lo:hi], async_op=True))
 
-    def step(self, img1, label20):
+    def step(self, img1, label20, next_img1=None):
+        """next_img1 (optional): the images of the NEXT call.  The part of their forward pass that depends on no trainable weight (conv1a and
+        the frozen b2 blocks) is then computed inside this step's loss phase, and the next call — which must pass that same tensor, unmodified —
+        starts from it.  Results are identical with and without it."""
         if not img1.is_cuda:
             raise RuntimeError("Trainer.step needs GPU tensors (no CPU fallback)")
         from . import loss_hip
         img1 = img1.contiguous().float()
-        img2 = second_view(img1)
+        pre, self._lookahead = getattr(self, "_lookahead", None), None
+        if pre is not None and pre["img1"].data_ptr() == img1.data_ptr() and pre["img1"].shape == img1.shape and pre["version"] == img1._version:
+            img2, prefix = pre["img2"], pre["prefix"]
+        else:
+            img2, prefix = second_view(img1), None
+        la = None
+        if next_img1 is not None and os.environ.get("WSEG_PREFETCH", "1") != "0":
+            n1 = next_img1.contiguous().float()
+            if n1.is_cuda and n1.shape == img1.shape:
+                la = {"img1": n1, "version": n1._version}
         self.optimizer.zero_grad(flat=False)                # (the fused step clears the flat gradient buffer itself, off the critical path)
         losses = loss_hip.step(self.model, img1, img2, label20, self.bg_threshold, self.rng, self.rng_parity,
-                               self.bg_topk_idx, zero_grads=True)
+                               self.bg_topk_idx, zero_grads=True, prefix=prefix, lookahead=la)
+        self._lookahead = la
         return self.finish_step(losses)
 
     def finish_step(self, losses):
