@@ -3,8 +3,14 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/look
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd "$ROOT"
-for n in 0 128 64; do
-  WSEG_PREFIX_TILE=$n timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --parity-steps 0 > "$OUT/b.json" 2> "$OUT/b.err" || { echo "bench failed"; tail -3 "$OUT/b.err"; }
-  echo "prefix tile $n: $(python -c "import json;d=json.load(open('$OUT/b.json'));print(d['ms_per_step'], d['roofline']['frac'])")"
+timeout -k 10 600 python -m pytest tests/test_gpu_loss.py tests/test_gpu_ddp_equivalence.py -m gpu -q -x > "$OUT/tests.log" 2>&1; echo "tests rc=$?"; tail -5 "$OUT/tests.log" | cut -c1-300
+for look in "" "--no-lookahead" "" "--no-lookahead"; do
+  timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --parity-steps 0 $look > "$OUT/b.json" 2> "$OUT/b.err" || { echo "bench failed"; tail -3 "$OUT/b.err"; }
+  echo "bench $look: $(python -c "import json;d=json.load(open('$OUT/b.json'));print(d['ms_per_step'], d['roofline']['frac'])")"
 done
-timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --parity-steps 0 --no-lookahead > "$OUT/b.json" 2> "$OUT/b.err"; echo "no lookahead: $(python -c "import json;d=json.load(open('$OUT/b.json'));print(d['ms_per_step'], d['roofline']['frac'])")"
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/tr" -o run -- python "$ROOT/bench.py" --steps 8 --warmup 3 --no-cpu-baseline --parity-steps 0 --no-lookahead > "$OUT/run.log" 2>&1 &&
+python "$ROOT/scripts/step_breakdown.py" $(find "$OUT/tr" -name run_kernel_trace.csv) 4 > "$OUT/breakdown.txt" 2>&1 &&
+python "$ROOT/scripts/step_timeline.py" $(find "$OUT/tr" -name run_kernel_trace.csv) > "$OUT/timeline.txt" 2>&1; echo "rc=$?"
+rm -rf "$OUT/tr"
+head -4 "$OUT/breakdown.txt"

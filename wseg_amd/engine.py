@@ -518,8 +518,8 @@ class Engine:
         assert all(x.shape[0] == N for x in xs)
         masks = self._masks(N, V, dev)
         S = {"masks": masks, "dims": {}, "N": N, "V": V, "dt": dt, "xs": xs, "lowres": lowres}
-        if prefix is None:
-            prefix = self._run_blocks(xs, None, 0, arch.N_FROZEN_BLOCKS, False, None)
+        if prefix is None:                                    # (the frozen blocks' activations are kept only for the tests' gate capture)
+            prefix = self._run_blocks(xs, None, 0, arch.N_FROZEN_BLOCKS, save and self.capture_ctx, S if (save and self.capture_ctx) else None)
         assert prefix["N"] == N and prefix["V"] == V and prefix["dt"] == dt, "run_forward: the prefix was computed for another batch shape / precision"
         S["dims"].update(prefix["sdims"])
         st = self._run_blocks(xs, prefix, arch.N_FROZEN_BLOCKS, len(arch.BLOCKS), save, S)
@@ -638,6 +638,7 @@ class Engine:
                 wstream = self._wgrad_stream = torch.cuda.Stream(dev)
             wstream.wait_stream(main)
         keep = []
+        pcm_join = [None]                                    # the PCM branch's stream until main has waited for it
 
         planes = {}                                          # split-bf16 mode: (hi, lo) bf16 planes of an f32 operand, made once per tensor
 
@@ -672,7 +673,7 @@ class Engine:
                     wgrad_launch(x, dy, self.flat_g[off:off + n], big_x3, **args)
                 else:
                     keep.append((x, dy))
-                    wstream.wait_event(main.record_event())
+                    wstream.wait_event(torch.cuda.current_stream(dev).record_event())      # (main, or the PCM branch's stream)
                     with torch.cuda.stream(wstream):
                         wgrad_launch(x, dy, self.flat_g[off:off + n], big_x3, **args)
 
@@ -682,6 +683,9 @@ class Engine:
             if self.block_done_hook is not None:
                 if wstream is not None:
                     main.wait_event(wstream.record_event())
+                if pcm_join[0] is not None:                  # the last bucket (b7 + heads) holds the PCM branch's f9 / f8_3 / f8_4 gradients
+                    main.wait_stream(pcm_join[0])
+                    pcm_join[0] = None
                 self.block_done_hook(nm)
 
         def dgrad(dy, wname, out, conv_cin, conv_cout, k, stride, dil, din, dout, **kw):
@@ -710,37 +714,49 @@ class Engine:
                 dr = g_rvd.contiguous().float() if dr is None else dr + g_rvd
             d_cam_low.append(dc)
             d_rvd.append(dr)
-        # ---- PCM branch -> f9, f8_3, f8_4
+        # ---- PCM branch -> f9, f8_3, f8_4.  It ends in WEIGHT gradients only (f8_3 / f8_4 read conv4 / conv5 detached, resnet38_contrast.py:63-64),
+        # so nothing of the backbone's backward pass waits for it: WSEG_PCM_STREAM=1 runs it on its own stream beside the first blocks (0.5 ms of small
+        # kernels + two PCM launches that otherwise sit in front of the head's data gradient), joined before the gradients are consumed.
+        pcm_stream = None
         if any(d is not None for d in d_rvd):
-            DN = torch.empty(M, 32, device=dev, dtype=torch.float32)
-            dFh = torch.zeros(M, 192, device=dev, dtype=torch.float32)
-            DNb = torch.empty(M, 32, device=dev, dtype=torch.bfloat16) if S["Fb"] is not None else None
-            for vw, dr in zip(S["views"], d_rvd):
-                if dr is None:
-                    continue
-                off, hw = vw["off"], vw["h"] * vw["w"]
-                if S["Fb"] is not None:
-                    L.pcm_backward_bf16(S["Fb"][off:], S["Gb"][off:], dr.contiguous(), vw["rvd"], vw["den"], DN[off:], DNb[off:], dFh[off:], N, hw)
-                else:
-                    L.pcm_backward(S["Fh"][off:], S["G"][off:], dr.contiguous(), vw["rvd"], vw["den"], DN[off:], dFh[off:], N, hw)
-            dF = E(M, 192)
-            L.l2norm_backward(S["Fm"], 192, dFh, S["nrm"], dF, 192, M)
-            if trainable("f9"):
-                g9 = torch.zeros(192, 195, device=dev, dtype=torch.float32)
-                L.conv_wgrad(S["feat"], dF, g9, N=N, IH=hdims[0][0], IW=hdims[0][1], IC=FEAT_LD, OH=hdims[0][0], OW=hdims[0][1], OC=192,
-                             KH=1, KW=1, IC_dw=195, seg2=seg(hdims, hdims), dtype=_cdt(dt))
-                gv = self.grad_view("f9").reshape(192, 195)
-                gv[:, 3:67] += g9[:, 0:64]
-                gv[:, 67:195] += g9[:, 64:192]
-                gv[:, 0:3] += g9[:, 192:195]
-            if trainable("f8_3") or trainable("f8_4"):
-                d_feat = E(M, FEAT_LD)
-                dgrad(dF, "f9", d_feat, FEAT_LD, 192, 1, 1, 1, hdims, hdims, epi=1, mask=S["feat"])
-                wgrad("f8_3", S["conv4"], d_feat, 512, 64, 1, 1, 1, hdims, hdims, ld_dy=FEAT_LD)
-                wgrad("f8_4", S["conv5"], d_feat.view(-1)[64:], 1024, 128, 1, 1, 1, hdims, hdims, ld_dy=FEAT_LD)
+            if os.environ.get("WSEG_PCM_STREAM", "0") == "1":   # (measured: -0.1..0.3 ms per step, but the conv launches it overlaps slow down: off by default)
+                pcm_stream = getattr(self, "_pcm_stream", None)
+                if pcm_stream is None or pcm_stream.device != dev:
+                    pcm_stream = self._pcm_stream = torch.cuda.Stream(dev)
+                pcm_stream.wait_stream(main)
+            with torch.cuda.stream(pcm_stream if pcm_stream is not None else main):
+                DN = torch.empty(M, 32, device=dev, dtype=torch.float32)
+                dFh = torch.zeros(M, 192, device=dev, dtype=torch.float32)
+                DNb = torch.empty(M, 32, device=dev, dtype=torch.bfloat16) if S["Fb"] is not None else None
+                for vw, dr in zip(S["views"], d_rvd):
+                    if dr is None:
+                        continue
+                    off, hw = vw["off"], vw["h"] * vw["w"]
+                    if S["Fb"] is not None:
+                        L.pcm_backward_bf16(S["Fb"][off:], S["Gb"][off:], dr.contiguous(), vw["rvd"], vw["den"], DN[off:], DNb[off:], dFh[off:], N, hw)
+                    else:
+                        L.pcm_backward(S["Fh"][off:], S["G"][off:], dr.contiguous(), vw["rvd"], vw["den"], DN[off:], dFh[off:], N, hw)
+                dF = E(M, 192)
+                L.l2norm_backward(S["Fm"], 192, dFh, S["nrm"], dF, 192, M)
+                if trainable("f9"):
+                    g9 = torch.zeros(192, 195, device=dev, dtype=torch.float32)
+                    L.conv_wgrad(S["feat"], dF, g9, N=N, IH=hdims[0][0], IW=hdims[0][1], IC=FEAT_LD, OH=hdims[0][0], OW=hdims[0][1], OC=192,
+                                 KH=1, KW=1, IC_dw=195, seg2=seg(hdims, hdims), dtype=_cdt(dt))
+                    gv = self.grad_view("f9").reshape(192, 195)
+                    gv[:, 3:67] += g9[:, 0:64]
+                    gv[:, 67:195] += g9[:, 64:192]
+                    gv[:, 0:3] += g9[:, 192:195]
+                if trainable("f8_3") or trainable("f8_4"):
+                    d_feat = E(M, FEAT_LD)
+                    dgrad(dF, "f9", d_feat, FEAT_LD, 192, 1, 1, 1, hdims, hdims, epi=1, mask=S["feat"])
+                    wgrad("f8_3", S["conv4"], d_feat, 512, 64, 1, 1, 1, hdims, hdims, ld_dy=FEAT_LD)
+                    wgrad("f8_4", S["conv5"], d_feat.view(-1)[64:], 1024, 128, 1, 1, 1, hdims, hdims, ld_dy=FEAT_LD)
+        pcm_join[0] = pcm_stream
         # ---- head
         if d_head_rows is None:
             if all(dc is None for dc in d_cam_low) and all(g[2] is None for g in grads):
+                if pcm_stream is not None:
+                    main.wait_stream(pcm_stream)
                 return
             d_head_rows = E(M, HEAD_LD)
             for vw, dc, g in zip(S["views"], d_cam_low, grads):
@@ -818,6 +834,8 @@ class Engine:
                 D = Din
                 block_done(name)
         planes.clear()
+        if pcm_join[0] is not None:
+            main.wait_stream(pcm_join[0])
         if wstream is not None:
             main.wait_stream(wstream)
             keep.clear()

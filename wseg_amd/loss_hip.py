@@ -26,7 +26,7 @@ def _side_streams(eng, dev):
     st = getattr(eng, "_side_streams", None)
     if st is None or st[0].device != dev:
         pr = int(os.environ.get("WSEG_SIDE_PRIO", "0"))
-        st = eng._side_streams = (torch.cuda.Stream(dev, priority=pr), torch.cuda.Stream(dev, priority=pr))
+        st = eng._side_streams = tuple(torch.cuda.Stream(dev, priority=pr) for _ in range(2))
     return st
 
 
@@ -121,12 +121,19 @@ def _maps_forward(v, label20, acc, N):
     L.up_norm_resize_forward(v.rvd, v.st_rv, label20, v.r, N, h, w, S, 128)
 
 
-def _maps_backward(v, label20, N):
+def _maps_backward_cam(v, label20, N):
+    """d(loss)/d(cam_low): cls + ER terms — needs er_ecr_prep's Gc only, not the ECR selection"""
     dev = v.cam_low.device
     S, h, w = v.S, v.h, v.w
     wy, wx = _adjoint_ones(h, S, dev), _adjoint_ones(w, S, dev)
     v.d_cam_low = _f32(N, 21, h, w, dev=dev)
     L.up_maps_backward(v.Gc, v.cam_low, v.st_cam, label20, v.bias, wy, wx, None, None, None, 0, 0.0, v.d_cam_low, N, h, w, S, 128)
+
+
+def _maps_backward_rv(v, label20, N):
+    """d(loss)/d(cam_rv_down): min-pool + ER + ECR terms"""
+    dev = v.cam_low.device
+    S, h, w = v.S, v.h, v.w
     v.d_rvd = _f32(N, 21, h, w, dev=dev)
     L.up_maps_backward(v.Gr, v.rvd, v.st_rv, label20, None, None, None, v.q, v.argc, v.res_min, v.k_min, 0.5 / (v.k_min * N),
                        v.d_rvd, N, h, w, S, 128)
@@ -250,57 +257,68 @@ def step(model, img1, img2, label20, bg_threshold=0.20, rng=None, rng_parity=Fal
         v.cam_low, v.rvd, v.head = cam_low, rvd, head
         views.append(v)
     v1, v2 = views
-    # per view, on its own stream: map losses (cls, min-pool, max-norm maps), then pseudo-labels + prototype candidates
+    # The loss phase is ~60 small dependent kernels; its critical path is what the step waits for.  HIP multiplexes its streams onto FOUR hardware
+    # queues (raising GPU_MAX_HW_QUEUES slows every conv launch: measured 37.0 -> 41-42 ms / step), one of which carries the weight packs (aux), so the
+    # independent branches are laid out on three lanes:
+    #   side[0]: map losses of view 1  M(1) -> [M(2)] -> ER / ECR chain -> map backward of view 1
+    #   side[1]: map losses of view 2  M(2) ------------------------^ -> hard-pixel weights of view 2 -> map backward of view 2
+    #   main:    pseudo-labels + prototype candidates of both views (they need only the forward outputs) -> prototypes -> record pass
+    #            -> [all-gather] -> hard-pixel weights of view 1 -> fused NCE -> [side 0, 1] -> head gradient -> backward pass
     cand = _f32(2, _CAND_L, dev=dev)
-    for vi, (v, st) in enumerate(zip(views, side)):
-        st.wait_event(fork)
-        with torch.cuda.stream(st):
+    for vi, v in enumerate(views):
+        side[vi].wait_event(fork)
+        with torch.cuda.stream(side[vi]):
             _maps_forward(v, label20, acc, N)
-            _candidates(v, label20, bg_threshold, tie_idx, N, cand[vi])
-    for st in side:
-        main.wait_stream(st)
+    for vi, v in enumerate(views):
+        _candidates(v, label20, bg_threshold, tie_idx, N, cand[vi])
     gathered = cand
     if distributed:                                         # global-batch prototypes: ONE all-gather of both views' candidates (694 KB)
         gathered = _f32(world, 2, _CAND_L, dev=dev)
         dist.all_gather_into_tensor(gathered.view(world * 2, _CAND_L), cand)
     for vi, v in enumerate(views):
         _merge_prototypes(v, gathered, vi, world)
-    # ---- pixel-to-prototype similarities + hard-pixel records on a side stream, concurrently with the ER / ECR chain below
+    # ---- ER + ECR on the 128x128 maps (both directions of the ECR top-k in ONE 2N-row selection), on side[0] behind both views' map losses
+    npix = 128 * 128
+    er_coef = 1.0 / (N * 20 * npix)
+    est = side[0]
+    est.wait_stream(side[1])
+    with torch.cuda.stream(est):
+        for v in views:
+            v.Gc = _f32(N, 21, 128, 128, dev=dev)
+        dlt = _f32(2 * N, 21 * npix, dev=dev)
+        L.er_ecr_prep(v1.c, v2.c, v1.r, v2.r, v1.Gc, v2.Gc, dlt[:N], dlt[N:], acc[2:3], N, npix, er_coef)
+        prep_done = est.record_event()
+        K_ecr = int(21 * npix * 0.2)
+        ws = torch.empty(L.select_workspace_bytes(2 * N), device=dev, dtype=torch.uint8)
+        res = _f32(2 * N, 4, dev=dev)
+        L.select_kth(dlt, 2 * N, 21 * npix, K_ecr, True, True, False, res, ws)
+        L.select_finish(res, 2 * N, K_ecr, False, 1.0 / (N * K_ecr), acc[3:4])
+        Gr = _f32(2 * N, 21, 128, 128, dev=dev)
+        L.ecr_backward(dlt, res, Gr, 2 * N, 21 * npix, K_ecr, 1.0 / (N * K_ecr))
+        v1.Gr, v2.Gr = Gr[:N], Gr[N:]
+        ecr_done = est.record_event()
+        _maps_backward_rv(v1, label20, N)
+    side[1].wait_event(prep_done)                           # both views' cam-map backward beside the ECR selection (side[1] is idle after M(2))
+    with torch.cuda.stream(side[1]):
+        _maps_backward_cam(v1, label20, N)
+        _maps_backward_cam(v2, label20, N)
+    # ---- pixel-to-prototype similarities + hard-pixel records (main stream, concurrently with the ER / ECR chain)
     # (the radix-select kernel is also the faster one on a single rank — 47 vs 118 us; the sort-based kernel remains the
     #  RNG-parity path, which replays the reference's host random stream)
     global_intra = distributed or (not rng_parity and os.environ.get("WSEG_INTRA_GLOBAL", "1") == "1")
     rank = dist.get_rank() if distributed else 0
     # record pass (similarities that only RANK pixels): exact-f32 MFMA in fp32 mode, split-bf16 products in the bf16 / bf16x3 modes
     nce_x3 = model.precision != "fp32" and os.environ.get("WSEG_NCE_X3", "1") != "0"
-    cst = side[1]
-    cst.wait_stream(main)
-    with torch.cuda.stream(cst):
-        # ONE launch for both views: per-pixel records {label, similarity to the pixel's own-class prototype, random key} straight from
-        # the raw features (csrc/loss.hip nce_records): the inputs of the hard-pixel sampling.  Over the GLOBAL batch under data
-        # parallelism (the reference samples on the gathered batch): the records (96 KB per rank for both views) are
-        # all-gathered, every rank finds the same global per-class order statistics and keeps the weights of its own pixels, scaled
-        # by `world` because the gradient all-reduce averages.
-        rec = _f32(2, 3, P, dev=dev)
-        for vi, v in enumerate(views):
-            v.rkey = _random_keys(P, rank, vi, dev) if global_intra else None
-        L.nce_records([dict(F=v.F, p_own=v.protos, y_own=v.y, rkey=v.rkey, rec=rec[vi]) for vi, v in enumerate(views)], P, split_bf16=nce_x3)
-        grec = rec
-    # ---- ER + ECR on the 128x128 maps (both directions of the ECR top-k in ONE 2N-row selection)
-    npix = 128 * 128
-    er_coef = 1.0 / (N * 20 * npix)
-    for v in views:
-        v.Gc = _f32(N, 21, 128, 128, dev=dev)
-    dlt = _f32(2 * N, 21 * npix, dev=dev)
-    L.er_ecr_prep(v1.c, v2.c, v1.r, v2.r, v1.Gc, v2.Gc, dlt[:N], dlt[N:], acc[2:3], N, npix, er_coef)
-    K_ecr = int(21 * npix * 0.2)
-    ws = torch.empty(L.select_workspace_bytes(2 * N), device=dev, dtype=torch.uint8)
-    res = _f32(2 * N, 4, dev=dev)
-    L.select_kth(dlt, 2 * N, 21 * npix, K_ecr, True, True, False, res, ws)
-    L.select_finish(res, 2 * N, K_ecr, False, 1.0 / (N * K_ecr), acc[3:4])
-    Gr = _f32(2 * N, 21, 128, 128, dev=dev)
-    L.ecr_backward(dlt, res, Gr, 2 * N, 21 * npix, K_ecr, 1.0 / (N * K_ecr))
-    v1.Gr, v2.Gr = Gr[:N], Gr[N:]
-    main.wait_stream(cst)
+    # ONE launch for both views: per-pixel records {label, similarity to the pixel's own-class prototype, random key} straight from
+    # the raw features (csrc/loss.hip nce_records): the inputs of the hard-pixel sampling.  Over the GLOBAL batch under data
+    # parallelism (the reference samples on the gathered batch): the records (96 KB per rank for both views) are
+    # all-gathered, every rank finds the same global per-class order statistics and keeps the weights of its own pixels, scaled
+    # by `world` because the gradient all-reduce averages.
+    rec = _f32(2, 3, P, dev=dev)
+    for vi, v in enumerate(views):
+        v.rkey = _random_keys(P, rank, vi, dev) if global_intra else None
+    L.nce_records([dict(F=v.F, p_own=v.protos, y_own=v.y, rkey=v.rkey, rec=rec[vi]) for vi, v in enumerate(views)], P, split_bf16=nce_x3)
+    grec = rec
     if global_intra and distributed:                        # (collectives stay on the main stream, in program order)
         grec = _f32(world, 2, 3, P, dev=dev)
         dist.all_gather_into_tensor(grec.view(world * 6, P), rec.view(6, P))
@@ -308,20 +326,24 @@ def step(model, img1, img2, label20, bg_threshold=0.20, rng=None, rng_parity=Fal
         for vi, v in enumerate(views):                     # view 1 fully before view 2 (RNG order of the reference)
             v.w_intra = _f32(P, dev=dev)
             L.intra_weights(v.y, rec[vi, 1], None, _rand_flags(v.y, rng, P), v.w_intra, P, ld_s=1)
-    # per view, again on its own stream: hard-pixel weights (a single-workgroup kernel) and the map backward
+    # hard-pixel weights (a single-workgroup kernel per view): view 1 here, view 2 on side[1] in front of its map backward
+    def weights_of(vi, v):
+        if global_intra:
+            v.w_intra = _f32(P, dev=dev)
+            L.intra_weights_global(grec.view(-1)[vi * 3 * P:], v.w_intra, P, world, rank, float(world), 6 * P)
+        elif not rng_parity:
+            v.w_intra = _f32(P, dev=dev)
+            L.intra_weights(v.y, rec[vi, 1], torch.rand(P, device=dev), None, v.w_intra, P, ld_s=1)
+
     fork2 = main.record_event()
-    for vi, (v, st) in enumerate(zip(views, side)):
-        st.wait_event(fork2)
-        with torch.cuda.stream(st):
-            if global_intra:
-                v.w_intra = _f32(P, dev=dev)
-                L.intra_weights_global(grec.view(-1)[vi * 3 * P:], v.w_intra, P, world, rank, float(world), 6 * P)
-            elif not rng_parity:
-                v.w_intra = _f32(P, dev=dev)
-                L.intra_weights(v.y, rec[vi, 1], torch.rand(P, device=dev), None, v.w_intra, P, ld_s=1)
-            _maps_backward(v, label20, N)
-    for st in side:
-        main.wait_stream(st)
+    weights_of(0, v1)
+    side[1].wait_event(fork2)
+    with torch.cuda.stream(side[1]):
+        weights_of(1, v2)
+        w2_done = side[1].record_event()
+        side[1].wait_event(ecr_done)
+        _maps_backward_rv(v2, label20, N)
+    main.wait_event(w2_done)
     # similarities, the three InfoNCE terms and dF of BOTH views in one launch (csrc/loss.hip nce_fused): features read once, only dF written
     for v in views:
         v.dF = _f32(P, 128, dev=dev)
@@ -329,6 +351,8 @@ def step(model, img1, img2, label20, bg_threshold=0.20, rng=None, rng_parity=Fal
                 P, 0.1 / (2 * P), 0.05, acc[4:7])
     # ---- into the network: one batched backward over both views
     d_head = torch.empty_like(ctx["head"])
+    main.wait_stream(side[0])
+    main.wait_stream(side[1])
     for v in views:
         L.head_grad_fused(v.dF, v.d_cam_low, v.head, d_head[v.off:], HEAD_LD, N, v.h, v.w, 16, 16)
     main.wait_stream(aux)
