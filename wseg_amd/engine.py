@@ -395,7 +395,7 @@ class Engine:
         outs, _ = self.run_forward([x], save=False, lowres=lowres)
         return outs[0]
 
-    def _run_blocks(self, xs, state, first, last, save, S, bm_hint=0):
+    def _run_blocks(self, xs, state, first, last, save, S):
         """Blocks arch.BLOCKS[first:last] (first == 0: conv1a first) over the batched views.  state: the dict an earlier call returned."""
         net = self.net
         V = len(xs)
@@ -422,7 +422,7 @@ class Engine:
         def conv(inp, wname, out, out2, cin, cout, k, stride, dil, din, dout, **kw):
             seg2 = (din[1][0], din[1][1], dout[1][0], dout[1][1]) if V == 2 else None
             L.conv_igemm(inp, P["w"][wname], out, out2, N=N, IH=din[0][0], IW=din[0][1], IC=cin, OH=dout[0][0], OW=dout[0][1],
-                         OC=cout, KH=k, KW=k, stride=stride, dil=dil, pad=dil * (k // 2), seg2=seg2, dtype=_cdt(dt), bm_hint=bm_hint, **kw)
+                         OC=cout, KH=k, KW=k, stride=stride, dil=dil, pad=dil * (k // 2), seg2=seg2, dtype=_cdt(dt), **kw)
 
         def next_bn(i):
             if i + 1 < len(arch.BLOCKS):
@@ -496,11 +496,11 @@ class Engine:
             t, xraw, dims = tn, xn, odims
         return dict(t=t, xraw=xraw, dims=dims, conv4=conv4, conv5=conv5, sdims=sdims, N=N, V=V, dt=dt)
 
-    def run_prefix(self, xs, bm_hint=0):
+    def run_prefix(self, xs):
         """The part of the forward pass that depends on no trainable weight: conv1a and the blocks Net.train() freezes (b2, b2_1, b2_2;
         resnet38_contrast.py:86-95 `not_training`), for one or two batched views.  Returns what run_forward continues from.  Because it depends only on the
         IMAGES, the fused step runs it for the NEXT batch on a side stream inside the loss phase of the current step (loss_hip.step `next_imgs`)."""
-        return self._run_blocks(xs, None, 0, arch.N_FROZEN_BLOCKS, False, None, bm_hint=bm_hint)
+        return self._run_blocks(xs, None, 0, arch.N_FROZEN_BLOCKS, False, None)
 
     def run_forward(self, xs, save, lowres=False, prefix=None):
         """xs: list of one or two image batches (same N).  Two views are BATCHED: every activation is one row

@@ -25,31 +25,16 @@ _TIE_CACHE = {}
 def _side_streams(eng, dev):
     st = getattr(eng, "_side_streams", None)
     if st is None or st[0].device != dev:
-        pr = int(os.environ.get("WSEG_SIDE_PRIO", "0"))
-        st = eng._side_streams = tuple(torch.cuda.Stream(dev, priority=pr) for _ in range(2))
+        st = eng._side_streams = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
     return st
 
 
 def _prefix_stream(eng, dev):
-    """Stream of the next batch's frozen prefix (step(lookahead=...)).  WSEG_PREFIX_CUS=n < 256: a CU-masked stream (hipExtStreamCreateWithCUMask,
-    the first n mask bits set; the mask bits go round-robin over the 8 XCDs, so every XCD keeps (256 - n) / 8 CUs free): the prefix tiles occupy whole
-    CUs (all registers, 160 KiB of LDS), and the loss phase's small dependent kernels otherwise wait for a tile to end before each launch."""
+    """Stream of the next batch's frozen prefix (step(lookahead=...)).  An ordinary stream: a high-priority or CU-masked one
+    (hipExtStreamCreateWithCUMask, to keep a few CUs free for the loss kernels) slowed EVERY conv launch of the step (36.1 -> 45-49 ms)."""
     st = getattr(eng, "_prefix_stream", None)
     if st is None or st.device != dev:
-        ncu = int(os.environ.get("WSEG_PREFIX_CUS", "256"))
-        if ncu >= 256:
-            st = torch.cuda.Stream(dev)
-        else:
-            import ctypes as C
-            hip = C.CDLL("libamdhip64.so")
-            words = (C.c_uint32 * 8)(*[(((1 << max(0, min(32, ncu - 32 * i))) - 1) & 0xFFFFFFFF) for i in range(8)])
-            h = C.c_void_p()
-            with torch.cuda.device(dev):
-                rc = hip.hipExtStreamCreateWithCUMask(C.byref(h), C.c_uint32(8), words)
-            if rc != 0:
-                raise RuntimeError(f"hipExtStreamCreateWithCUMask failed ({rc})")
-            st = torch.cuda.ExternalStream(h.value, device=dev)
-        eng._prefix_stream = st
+        st = eng._prefix_stream = torch.cuda.Stream(dev)
     return st
 
 
@@ -237,7 +222,7 @@ def step(model, img1, img2, label20, bg_threshold=0.20, rng=None, rng_parity=Fal
         with torch.cuda.stream(pst):
             n1 = lookahead["img1"]
             n2 = second_view(n1, img2.shape[-1])
-            lookahead["img2"], lookahead["prefix"] = n2, eng.run_prefix([n1, n2], bm_hint=int(os.environ.get("WSEG_PREFIX_TILE", "0")))
+            lookahead["img2"], lookahead["prefix"] = n2, eng.run_prefix([n1, n2])
         for t_ in (n2, lookahead["prefix"]["t"]):           # allocated on the prefix stream, consumed on the caller's in the next step
             t_.record_stream(main)
     # Backward-only preparation — the transposed weight packs (420 MB of traffic) and the gradient memset (420 MB) — on a third
