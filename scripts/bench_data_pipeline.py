@@ -76,15 +76,24 @@ if torch.cuda.is_available():
                         lr=lr, weight_decay=5e-4, max_step=10000)
     model.load_state_dict(synth.procedural_state_dict(0, device="cuda")); model.cuda(); model.train()
     tr = Trainer(model, opt, 0.20, random.Random(0), False)
+
+    def run_ahead(batches):
+        """steps over an iterator of (img, lab) device batches, one batch ahead (Trainer.step next_img1); returns the images stepped"""
+        n, cur = 0, next(batches, None)
+        while cur is not None:
+            nxt = next(batches, None)
+            tr.step(cur[0], cur[1], next_img1=nxt[0] if nxt is not None else None)
+            n += cur[0].shape[0]
+            cur = nxt
+        return n
+
     for nw in workers:
         it = iter(loader(nw))
         pack = next(it)
         tr.step(pack[1].cuda(non_blocking=True), pack[2].cuda(non_blocking=True))
         torch.cuda.synchronize()
-        t0 = time.perf_counter(); n = 0
-        for pack in it:
-            tr.step(pack[1].cuda(non_blocking=True), pack[2].cuda(non_blocking=True))
-            n += pack[1].shape[0]
+        t0 = time.perf_counter()
+        n = run_ahead((pack[1].cuda(non_blocking=True), pack[2].cuda(non_blocking=True)) for pack in it)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         print(f"JPEG files -> training step (B = {B}, bf16), {nw:2d} workers: {n / dt:7.1f} images/s", flush=True)
@@ -94,10 +103,8 @@ if torch.cuda.is_available():
         img, lab = next(it)
         tr.step(img, lab)
         torch.cuda.synchronize()
-        t0 = time.perf_counter(); n = 0
-        for img, lab in it:
-            tr.step(img, lab)
-            n += img.shape[0]
+        t0 = time.perf_counter()
+        n = run_ahead(it)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         print(f"JPEG files -> device augmentation ({'one batch ahead on a side stream' if overlap else 'same stream'}) -> training step (B = {B}, bf16), {nw:2d} workers: {n / dt:7.1f} images/s", flush=True)

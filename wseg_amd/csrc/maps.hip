@@ -70,23 +70,61 @@ __global__ __launch_bounds__(256) void up_stats_partial_kernel(const float* __re
   const int r0 = ck * per, r1 = min(S, r0 + per);
   const int tpr = threads_per_row(S), rpi = 256 / tpr;
   const int tr = tid / tpr, tx = tid & (tpr - 1);
-  unsigned long long mx = 0ull, mn = ~0ull;
+  // A thread owns COLUMNS (ox = tx, tx + tpr, ...: at most MAXC) and walks its rows downwards, so the x-interpolated values of the two low-res rows
+  // in use — the `a` and `b` of up_value, the SAME expressions — are recomputed only when the low-res row changes (every ~S/h rows; moving down one
+  // low-res row turns b into a), and a value costs one multiply + one fma.  Indices grow along the walk, so "first occurrence wins a tie" is a strict
+  // compare on the value; the 64-bit keys are packed once at the end.
+  constexpr int MAXC = 4;
+  int x0[MAXC], x1[MAXC]; float fx[MAXC], ra[MAXC], rb[MAXC];
+  int nc = 0;
+  for (int ox = tx; ox < S && nc < MAXC; ox += tpr, ++nc) src_index(ox, sx, w, x0[nc], x1[nc], fx[nc]);
+  unsigned mxv = 0u, mxi = 0u, mnv = 0xFFFFFFFFu, mni = 0xFFFFFFFFu;
+  bool any = false;
   float sum = 0.f;
+  int cy0 = -1, cy1 = -1;
   for (int oy = r0 + tr; oy < r1; oy += rpi) {
     int y0, y1; float fy;
     src_index(oy, sy, h, y0, y1, fy);
-    for (int ox = tx; ox < S; ox += tpr) {
-      int x0, x1; float fx;
-      src_index(ox, sx, w, x0, x1, fx);
-      const float u = up_value(p, w, y0, y1, x0, x1, fy, fx);
+    if (y0 != cy0 || y1 != cy1) {
+#pragma unroll
+      for (int j = 0; j < MAXC; ++j)
+        if (j < nc) {
+          ra[j] = (y0 == cy1) ? rb[j] : __fmaf_rn(fx[j], p[y0 * w + x1[j]], __fmul_rn(1.f - fx[j], p[y0 * w + x0[j]]));
+          rb[j] = (y1 == y0) ? ra[j] : __fmaf_rn(fx[j], p[y1 * w + x1[j]], __fmul_rn(1.f - fx[j], p[y1 * w + x0[j]]));
+        }
+      cy0 = y0; cy1 = y1;
+    }
+#pragma unroll
+    for (int j = 0; j < MAXC; ++j)
+      if (j < nc) {
+        const float u = __fmaf_rn(fy, rb[j], __fmul_rn(1.f - fy, ra[j]));
+        const unsigned i = (unsigned)(oy * S + tx + j * tpr);
+        const unsigned vb = __float_as_uint(fmaxf(u, 0.f));
+        sum += u;
+        if (!any || vb > mxv) { mxv = vb; mxi = i; }
+        if (!any || vb < mnv) { mnv = vb; mni = i; }
+        any = true;
+      }
+  }
+  // columns beyond MAXC * tpr (S > 1024): the plain form
+  for (int oy = r0 + tr; oy < r1; oy += rpi) {
+    int y0, y1; float fy;
+    src_index(oy, sy, h, y0, y1, fy);
+    for (int ox = tx + MAXC * tpr; ox < S; ox += tpr) {
+      int xa, xb; float f;
+      src_index(ox, sx, w, xa, xb, f);
+      const float u = up_value(p, w, y0, y1, xa, xb, fy, f);
       const unsigned i = (unsigned)(oy * S + ox);
-      const unsigned rb = __float_as_uint(fmaxf(u, 0.f));
+      const unsigned vb = __float_as_uint(fmaxf(u, 0.f));
       sum += u;
-      const unsigned long long a = ((unsigned long long)rb << 32) | (unsigned)(~i), b = ((unsigned long long)rb << 32) | i;
-      mx = a > mx ? a : mx; mn = b < mn ? b : mn;
+      if (!any || vb > mxv || (vb == mxv && i < mxi)) { mxv = vb; mxi = i; }
+      if (!any || vb < mnv || (vb == mnv && i < mni)) { mnv = vb; mni = i; }
+      any = true;
     }
   }
-  s_mx[tid] = mx; s_mn[tid] = mn; s_sum[tid] = sum;
+  s_mx[tid] = any ? (((unsigned long long)mxv << 32) | (unsigned)(~mxi)) : 0ull;
+  s_mn[tid] = any ? (((unsigned long long)mnv << 32) | mni) : ~0ull;
+  s_sum[tid] = sum;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
     if (tid < o) {
