@@ -45,16 +45,46 @@ def main(argv=None):
     ds = wdata.VOC12ClsDatasetMSF(args.infer_list, args.voc12_root, args.labels, scales=[0.5, 1.0, 1.5, 2.0],
                                   inter_transform=[np.asarray, model.normalize, wdata.HWC_to_CHW])
     loader = torch.utils.data.DataLoader(ds, shuffle=False, num_workers=args.num_workers, pin_memory=True)
+    # One image behind: the device work of image i is enqueued (nothing in infer_image synchronises), its outputs start their way to pinned host
+    # buffers, and only then are the files of image i - 1 written — the png / npy writes and the loader hand-over overlap the GPU instead of
+    # alternating with it (the reference's loop, contrast_infer.py:52-99, syncs per image on `.cpu()`).
+    def start(img_name, pred, cam_dict):
+        host_pred = torch.empty(pred.shape, dtype=pred.dtype, pin_memory=True)
+        host_pred.copy_(pred, non_blocking=True)
+        host_cams = None
+        if args.out_cam is not None:
+            host_cams = {}
+            for k, v in cam_dict.items():
+                h = torch.empty(v.shape, dtype=v.dtype, pin_memory=True)
+                h.copy_(v, non_blocking=True)
+                host_cams[k] = h
+        ev = torch.cuda.Event()
+        ev.record()
+        return img_name, host_pred, host_cams, ev
+
+    def finish(item):
+        img_name, host_pred, host_cams, ev = item
+        ev.synchronize()
+        if host_cams is not None:
+            np.save(os.path.join(args.out_cam, img_name + '.npy'), {k: v.numpy() for k, v in host_cams.items()})
+        if args.out_cam_pred is not None:
+            PIL.Image.fromarray(host_pred.numpy()).save(os.path.join(args.out_cam_pred, img_name + '.png'))
+
+    for d in (args.out_cam, args.out_cam_pred):
+        if d is not None:
+            os.makedirs(d, exist_ok=True)
+    pending = None
     for it, (img_name, img_list, label) in enumerate(loader):
         img_name, label = img_name[0], label[0]
-        orig = np.asarray(PIL.Image.open(wdata.get_img_path(img_name, args.voc12_root)))
-        norm_cam, pred, cam_dict = infer_image(model, img_list, label, orig.shape[:2], args.out_cam_pred_alpha)
-        if args.out_cam is not None:
-            os.makedirs(args.out_cam, exist_ok=True)
-            np.save(os.path.join(args.out_cam, img_name + '.npy'), {k: v.cpu().numpy() for k, v in cam_dict.items()})
-        if args.out_cam_pred is not None:
-            os.makedirs(args.out_cam_pred, exist_ok=True)
-            PIL.Image.fromarray(pred.cpu().numpy()).save(os.path.join(args.out_cam_pred, img_name + '.png'))
+        with PIL.Image.open(wdata.get_img_path(img_name, args.voc12_root)) as im:      # (header only: the reference decodes the image again for its shape)
+            W, H = im.size
+        norm_cam, pred, cam_dict = infer_image(model, img_list, label, (H, W), args.out_cam_pred_alpha)
+        item = start(img_name, pred, cam_dict)
+        if pending is not None:
+            finish(pending)
+        pending = item
+    if pending is not None:
+        finish(pending)
 
 
 if __name__ == '__main__':

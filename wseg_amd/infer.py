@@ -15,11 +15,11 @@ def infer_image(model, img_list, label20, orig_size, alpha=0.26):
     returns (norm_cam [20,H,W] f32, pred [H,W] uint8, cam_dict {class: map}) — device tensors."""
     dev = next(model.parameters()).device
     H, W = orig_size
-    lab = label20.to(dev).float().contiguous()
+    lab = label20.to(dev, non_blocking=True).float().contiguous()
     sum_cam = torch.zeros(20, H, W, device=dev, dtype=torch.float32)
     imgs = []
     for img in img_list:
-        img = torch.as_tensor(img).to(dev).float()
+        img = torch.as_tensor(img).to(dev, non_blocking=True).float()     # (pinned loader batches: asynchronous)
         imgs.append(img.unsqueeze(0) if img.dim() == 3 else img)
     # an image and its flipped copy (same size, consecutive in the MSF order) go through the net as ONE batch of two: every op
     # of the eval forward is per image, so the maps are those of two separate forwards (contrast_infer.py:58-66 runs 8)
