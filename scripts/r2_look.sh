@@ -3,7 +3,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/look
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd "$ROOT"
-timeout -k 10 900 python -m pytest tests/test_gpu_loss.py tests/test_gpu_ddp_equivalence.py tests/test_gpu_infer_cli.py -m gpu -q -x > "$OUT/tests.log" 2>&1; echo "tests rc=$?"; tail -5 "$OUT/tests.log" | cut -c1-300
+timeout -k 10 900 python -m pytest tests/test_gpu_loss.py tests/test_gpu_ddp_equivalence.py tests/test_gpu_infer_cli.py tests/test_gpu_net.py tests/test_gpu_contract.py -m gpu -q -x > "$OUT/tests.log" 2>&1; echo "tests rc=$?"; tail -5 "$OUT/tests.log" | cut -c1-300
 for look in "" "--no-lookahead" ""; do
   timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --parity-steps 0 $look > "$OUT/b.json" 2> "$OUT/b.err" || { echo "bench failed"; tail -3 "$OUT/b.err"; }
   echo "bench $look: $(python -c "import json;d=json.load(open('$OUT/b.json'));print(d['ms_per_step'], d['roofline']['frac'])")"

@@ -201,15 +201,17 @@ class Engine:
         L.pack_x3(w32.contiguous(), out)
         return out
 
-    def ensure_packs(self, device, dt, defer_wt=False):
+    def ensure_packs(self, device, dt, defer_wt=False, late_stream=None):
         with self.lock:
-            return self._ensure_packs(device, dt, defer_wt)
+            return self._ensure_packs(device, dt, defer_wt, late_stream)
 
-    def _ensure_packs(self, device, dt, defer_wt=False):
+    def _ensure_packs(self, device, dt, defer_wt=False, late_stream=None):
         """Packed (cast / transposed) weights + folded BatchNorms.  Frozen pieces (every BN, conv1a, b2*) are
         cached on their own key so a training step only re-packs the 40 trainable tensors.
         defer_wt: the transposed (dgrad) packs are only needed by the backward pass — the fused training step lets
-        `finish_packs()` make them on a side stream during the loss phase, when the chip is mostly idle."""
+        `finish_packs()` make them on a side stream during the loss phase, when the chip is mostly idle.
+        late_stream: the packs the forward pass needs only from b5 on (the K-concatenated skip packs, the head, f9: ~10 small launches that would
+        otherwise sit in front of every step) are made on that stream; the forward pass waits for them where it first uses one (`_join_late_packs`)."""
         net = self.net
         tdt = L.TORCH_DTYPE[dt]
         frozen_names = [c[0] for b in arch.BLOCKS if b[0] in arch.FROZEN_BLOCKS for c in arch.block_convs(b)]
@@ -288,44 +290,62 @@ class Engine:
                 P["w"][cname] = mirror[off:off + n].view(co, T, ci)
                 if cname not in no_dgrad:
                     P["wt"][cname] = (self.flat_wt3 if dt == L.F32X3 else self.flat_wt)[off:off + n].view(ci, T, co)
-        # bottleneck blocks (b6, b7), bf16 mode: skip conv and last conv as ONE two-source product (K-concatenation):
-        # rows [W_branch1[oc] | W_branch2b2[oc]] — the skip output is then neither written nor re-read (444 MB each way for b7)
-        if dt == L.BF16 and FUSE_SKIP:
-            for b in arch.BLOCKS:                               # (b5: the residual-block form — 3x3 last conv + 1x1 skip conv at stride 1)
-                if b[1] == "res" and b[0] not in arch.FROZEN_BLOCKS and not arch.block_same_shape(b) and b[5] == 1 and b[4] % 256 == 0 and b[2] % 256 == 0:
-                    nm, cin_, mid_, cout_ = b[0], b[2], b[3], b[4]
-                    P["w"][nm + ".skip_fused"] = torch.cat([P["w"][nm + ".conv_branch2b1"].reshape(cout_, 9 * mid_),
-                                                             P["w"][nm + ".conv_branch1"].reshape(cout_, cin_)], dim=1)
-            for b in arch.BLOCKS:
-                if b[1] != "res" and b[0] not in arch.FROZEN_BLOCKS and b[2] == b[4] // 2 and b[5] == 1 and b[4] % 256 == 0:
-                    P["w"][b[0] + ".skip_fused"] = torch.cat([P["w"][b[0] + ".conv_branch1"], P["w"][b[0] + ".conv_branch2b2"]], dim=1)
-        # fused head: rows [fc_proj | fc8 | 0]; its transposed pack is made from the two f32 masters directly
-        wh = torch.zeros(HEAD_LD, 1, 4096, device=device, dtype=tdt)
-        wht = torch.zeros(4096, 1, HEAD_LD, device=device, dtype=tdt)
-        pdt = L.F32 if dt == L.F32X3 else dt                  # (split-bf16: f32 packs first, split below)
-        L.pack_weights(net.fc_proj.weight.detach(), wh, None, 128, 1, 4096, 128, 4096, pdt)
-        L.pack_weights(net.fc8.weight.detach(), wh[128:], None, 21, 1, 4096, 21, 4096, pdt)
-        off, _ = self.offsets["fc_proj"]                     # fc_proj and fc8 are adjacent in flat_w: one [149,4096] master
-        L.pack_weights(self.flat_w[off:off + 149 * 4096], None, wht, 149, 1, 4096, HEAD_LD, 4096, pdt)
-        if dt == L.F32X3:
-            wh, wht = self._x3(wh), self._x3(wht)
-        P["w"]["head"], P["wt"]["head"] = wh, wht
-        for nm, (co, ci) in (("f8_3", (64, 512)), ("f8_4", (128, 1024))):
-            off, n = self.offsets[nm]
-            P["w"][nm] = mirror[off:off + n].view(co, 1, ci)
-        # f9: input columns re-ordered to the internal feature layout [f8_3 | f8_4 | x_s | pad]
-        w9 = net.f9.weight.detach().reshape(192, 195)
-        w9p = torch.cat([w9[:, 3:67], w9[:, 67:195], w9[:, 0:3]], dim=1).contiguous()
-        wf = torch.empty(192, 1, FEAT_LD, device=device, dtype=tdt)
-        wt = torch.empty(FEAT_LD, 1, 192, device=device, dtype=tdt)
-        L.pack_weights(w9p, wf, wt, 192, 1, 195, 192, FEAT_LD, pdt)
-        if dt == L.F32X3:
-            wf, wt = self._x3(wf), self._x3(wt)
-        P["w"]["f9"], P["wt"]["f9"] = wf, wt
+        def late():
+            # bottleneck blocks (b6, b7), bf16 mode: skip conv and last conv as ONE two-source product (K-concatenation):
+            # rows [W_branch1[oc] | W_branch2b2[oc]] — the skip output is then neither written nor re-read (444 MB each way for b7)
+            if dt == L.BF16 and FUSE_SKIP:
+                for b in arch.BLOCKS:                               # (b5: the residual-block form — 3x3 last conv + 1x1 skip conv at stride 1)
+                    if b[1] == "res" and b[0] not in arch.FROZEN_BLOCKS and not arch.block_same_shape(b) and b[5] == 1 and b[4] % 256 == 0 and b[2] % 256 == 0:
+                        nm, cin_, mid_, cout_ = b[0], b[2], b[3], b[4]
+                        P["w"][nm + ".skip_fused"] = torch.cat([P["w"][nm + ".conv_branch2b1"].reshape(cout_, 9 * mid_),
+                                                                 P["w"][nm + ".conv_branch1"].reshape(cout_, cin_)], dim=1)
+                for b in arch.BLOCKS:
+                    if b[1] != "res" and b[0] not in arch.FROZEN_BLOCKS and b[2] == b[4] // 2 and b[5] == 1 and b[4] % 256 == 0:
+                        P["w"][b[0] + ".skip_fused"] = torch.cat([P["w"][b[0] + ".conv_branch1"], P["w"][b[0] + ".conv_branch2b2"]], dim=1)
+            # fused head: rows [fc_proj | fc8 | 0]; its transposed pack is made from the two f32 masters directly
+            wh = torch.zeros(HEAD_LD, 1, 4096, device=device, dtype=tdt)
+            wht = torch.zeros(4096, 1, HEAD_LD, device=device, dtype=tdt)
+            pdt = L.F32 if dt == L.F32X3 else dt                  # (split-bf16: f32 packs first, split below)
+            L.pack_weights(net.fc_proj.weight.detach(), wh, None, 128, 1, 4096, 128, 4096, pdt)
+            L.pack_weights(net.fc8.weight.detach(), wh[128:], None, 21, 1, 4096, 21, 4096, pdt)
+            off, _ = self.offsets["fc_proj"]                     # fc_proj and fc8 are adjacent in flat_w: one [149,4096] master
+            L.pack_weights(self.flat_w[off:off + 149 * 4096], None, wht, 149, 1, 4096, HEAD_LD, 4096, pdt)
+            if dt == L.F32X3:
+                wh, wht = self._x3(wh), self._x3(wht)
+            P["w"]["head"], P["wt"]["head"] = wh, wht
+            for nm, (co, ci) in (("f8_3", (64, 512)), ("f8_4", (128, 1024))):
+                off, n = self.offsets[nm]
+                P["w"][nm] = mirror[off:off + n].view(co, 1, ci)
+            # f9: input columns re-ordered to the internal feature layout [f8_3 | f8_4 | x_s | pad]
+            w9 = net.f9.weight.detach().reshape(192, 195)
+            w9p = torch.cat([w9[:, 3:67], w9[:, 67:195], w9[:, 0:3]], dim=1).contiguous()
+            wf = torch.empty(192, 1, FEAT_LD, device=device, dtype=tdt)
+            wt = torch.empty(FEAT_LD, 1, 192, device=device, dtype=tdt)
+            L.pack_weights(w9p, wf, wt, 192, 1, 195, 192, FEAT_LD, pdt)
+            if dt == L.F32X3:
+                wf, wt = self._x3(wf), self._x3(wt)
+            P["w"]["f9"], P["wt"]["f9"] = wf, wt
+
+        # (the names exist at once — the forward pass tests `in P["w"]` — their contents when `_late_ev` has been waited for)
+        self._late_ev = None
+        if late_stream is not None:
+            cur = torch.cuda.current_stream(device)
+            late_stream.wait_stream(cur)
+            with torch.cuda.stream(late_stream):
+                late()
+            self._late_ev = late_stream.record_event()
+        else:
+            late()
         self.packs, self.pack_key = P, key
         if not defer_wt:
             self.finish_packs()
         return P
+
+    def _join_late_packs(self, device):
+        ev = getattr(self, "_late_ev", None)
+        if ev is not None:
+            torch.cuda.current_stream(device).wait_event(ev)
+            self._late_ev = None
 
     def finish_packs(self):
         """The transposed (dgrad) packs [IC][T][OC] of the current weights: ONE launch over all layers into the flat buffer the
@@ -444,6 +464,8 @@ class Engine:
             b = arch.BLOCKS[i]
             name, kind, cin, mid, cout, stride, fd, d, p = b
             same = arch.block_same_shape(b)
+            if (name + ".skip_fused") in P["w"]:
+                self._join_late_packs(dev)
             (nsc, nsh), ndrop = next_bn(i)
             nxt_same = i + 1 < len(arch.BLOCKS) and arch.block_same_shape(arch.BLOCKS[i + 1])
             k0 = 3 if kind == "res" else 1
@@ -544,6 +566,7 @@ class Engine:
                          OC=cout, KH=k, KW=k, stride=stride, dil=dil, pad=dil * (k // 2), seg2=seg2, dtype=_cdt(dt), **kw)
 
         fea = t                                               # relu(bn7(x)) * dropout7   [M,4096]
+        self._join_late_packs(dev)
         M = rows_of(dims)
         offs = offs_of(dims)
         head = E(M, HEAD_LD)

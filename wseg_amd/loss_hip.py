@@ -201,14 +201,14 @@ def step(model, img1, img2, label20, bg_threshold=0.20, rng=None, rng_parity=Fal
     eng.attach_grads()
     defer = os.environ.get("WSEG_DEFER_PACKS", "1") != "0"      # (0: A/B switch — packs and memset before the forward pass)
     from .engine import DT_OF
-    eng.ensure_packs(dev, DT_OF[model.precision], defer_wt=defer)
+    use_streams = os.environ.get("WSEG_STREAMS", "1") != "0"
+    eng.ensure_packs(dev, DT_OF[model.precision], defer_wt=defer, late_stream=_aux_stream(eng, dev) if (defer and use_streams) else None)
     if zero_grads and not defer:
         eng.flat_g.zero_()
     acc = torch.zeros(8, device=dev, dtype=torch.float32)   # [cls1+cls2, (rvmin1+rvmin2)/2, er_sum, ecr, cross, cross2, intra]
     # The two views are independent until ER/ECR: run each on its own HIP stream so the small 128x128 view's
     # launches (which cannot fill 256 CUs) overlap with the 448x448 view's.
     main = torch.cuda.current_stream(dev)
-    use_streams = os.environ.get("WSEG_STREAMS", "1") != "0"
     side = _side_streams(eng, dev) if use_streams else (main, main)
     # Both views go through the network in ONE batched pass (two row segments per launch); the per-view map
     # losses then run on their own HIP streams.
