@@ -130,6 +130,26 @@ def test_train_forward_backward(nets, proc_sd, prec):
     m.eval()
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_forward_from_a_precomputed_prefix(nets, prec):
+    """Engine.run_prefix (conv1a + the frozen b2 blocks, computed ahead by the fused step's lookahead) followed by run_forward(prefix=...) gives the
+    same bits as one run_forward — one view and the batched two-view form, odd sizes; a prefix of another batch shape is refused."""
+    from wseg_amd import synth
+    m = nets[prec].eval()
+    eng = m._engine
+    with torch.no_grad():
+        for xs in ([synth.synthetic_images(2, 96, 3).cuda()], [synth.synthetic_images(2, 104, 4).cuda(), synth.synthetic_images(2, 56, 5).cuda()]):
+            eng.ensure_flat(xs[0].device)
+            ref, _ = eng.run_forward(xs, save=False, lowres=True)
+            pre = eng.run_prefix(xs)
+            got, _ = eng.run_forward(xs, save=False, lowres=True, prefix=pre)
+            for a, b in zip(ref, got):
+                for t, u in zip(a, b):
+                    assert torch.equal(t, u)
+        with pytest.raises(AssertionError):
+            eng.run_forward([synth.synthetic_images(1, 96, 3).cuda()], save=False, lowres=True, prefix=pre)
+
+
 def test_state_dict_roundtrip_and_no_cpu_fallback(nets, proc_sd):
     m = nets["fp32"]
     sd2 = m.state_dict()

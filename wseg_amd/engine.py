@@ -415,7 +415,7 @@ class Engine:
         outs, _ = self.run_forward([x], save=False, lowres=lowres)
         return outs[0]
 
-    def _run_blocks(self, xs, state, first, last, save, S):
+    def _run_blocks(self, xs, state, first, last, save, S, final_t=None):
         """Blocks arch.BLOCKS[first:last] (first == 0: conv1a first) over the batched views.  state: the dict an earlier call returned."""
         net = self.net
         V = len(xs)
@@ -476,7 +476,8 @@ class Engine:
                 v = E(Mo, mid)
                 conv(t, name + ".conv_branch2a", None, v, cin, mid, 3, stride, fd, dims, odims, scale=s1, shift=sh1)
                 xn = E(Mo, cout) if nxt_same else None
-                tn = E(Mo, cout)
+                tn = final_t if (final_t is not None and i == last - 1) else E(Mo, cout)
+                assert tn.shape == (Mo, cout) and tn.dtype == tdt
                 if (name + ".skip_fused") in P["w"]:            # last conv + 1x1 skip conv as one two-source launch
                     conv(v, name + ".skip_fused", xn, tn, mid, cout, 3, 1, d, odims, odims, in2=t, IC2=cin, scale=nsc, shift=nsh, drop=ndrop)
                 else:
@@ -516,13 +517,26 @@ class Engine:
             if name == "b6":
                 conv5 = t
             t, xraw, dims = tn, xn, odims
-        return dict(t=t, xraw=xraw, dims=dims, conv4=conv4, conv5=conv5, sdims=sdims, N=N, V=V, dt=dt)
+        return dict(t=t, xraw=xraw, dims=dims, conv4=conv4, conv5=conv5, sdims=sdims, N=N, V=V, dt=dt,
+                    in_dims=state["in_dims"] if state is not None else [tuple(x.shape[2:]) for x in xs])
 
-    def run_prefix(self, xs):
+    def prefix_out_shape(self, xs):
+        """(rows, channels) of run_prefix's result for these views"""
+        N = xs[0].shape[0]
+        dims = [tuple(x.shape[2:]) for x in xs]
+        for b in arch.BLOCKS[:arch.N_FROZEN_BLOCKS]:
+            name, kind, cin, mid, cout, stride, fd, d, p = b
+            k0 = 3 if kind == "res" else 1
+            dims = [(_out_size(h, k0, stride, fd if kind == "res" else 1), _out_size(w, k0, stride, fd if kind == "res" else 1)) for (h, w) in dims]
+        return sum(N * h * w for (h, w) in dims), arch.BLOCKS[arch.N_FROZEN_BLOCKS - 1][4]
+
+    def run_prefix(self, xs, out=None):
         """The part of the forward pass that depends on no trainable weight: conv1a and the blocks Net.train() freezes (b2, b2_1, b2_2;
         resnet38_contrast.py:86-95 `not_training`), for one or two batched views.  Returns what run_forward continues from.  Because it depends only on the
-        IMAGES, the fused step runs it for the NEXT batch on a side stream inside the loss phase of the current step (loss_hip.step `next_imgs`)."""
-        return self._run_blocks(xs, None, 0, arch.N_FROZEN_BLOCKS, False, None)
+        IMAGES, the fused step runs it for the NEXT batch on a side stream inside the loss phase of the current step (loss_hip.step `lookahead`).
+        out: a [prefix_out_shape] tensor for the result — the fused step allocates it on the CALLER's stream, so that the one tensor that crosses from the
+        prefix stream to the next step belongs to the caller's allocator pool (no record_stream bookkeeping: with it the reserved memory grew by 6 GB)."""
+        return self._run_blocks(xs, None, 0, arch.N_FROZEN_BLOCKS, False, None, final_t=out)
 
     def run_forward(self, xs, save, lowres=False, prefix=None):
         """xs: list of one or two image batches (same N).  Two views are BATCHED: every activation is one row
@@ -542,7 +556,8 @@ class Engine:
         S = {"masks": masks, "dims": {}, "N": N, "V": V, "dt": dt, "xs": xs, "lowres": lowres}
         if prefix is None:                                    # (the frozen blocks' activations are kept only for the tests' gate capture)
             prefix = self._run_blocks(xs, None, 0, arch.N_FROZEN_BLOCKS, save and self.capture_ctx, S if (save and self.capture_ctx) else None)
-        assert prefix["N"] == N and prefix["V"] == V and prefix["dt"] == dt, "run_forward: the prefix was computed for another batch shape / precision"
+        assert prefix["N"] == N and prefix["V"] == V and prefix["dt"] == dt and prefix["in_dims"] == [tuple(x.shape[2:]) for x in xs], \
+            "run_forward: the prefix was computed for another batch shape / precision"
         S["dims"].update(prefix["sdims"])
         st = self._run_blocks(xs, prefix, arch.N_FROZEN_BLOCKS, len(arch.BLOCKS), save, S)
         t, dims, conv4, conv5 = st["t"], st["dims"], st["conv4"], st["conv5"]

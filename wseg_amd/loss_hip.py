@@ -216,15 +216,17 @@ def step(model, img1, img2, label20, bg_threshold=0.20, rng=None, rng_parity=Fal
     fork = main.record_event()
     pst = None
     if lookahead is not None:
-        from .train import second_view
         pst = _prefix_stream(eng, dev)
+        n1 = lookahead["img1"]
+        # the two tensors that cross from the prefix stream into the next step are allocated HERE, on the caller's stream (its allocator pool: they are
+        # written on the prefix stream, which the caller waits for before its backward pass, and freed in the caller's program order)
+        n2 = torch.empty(n1.shape[0], n1.shape[1], img2.shape[-2], img2.shape[-1], device=dev, dtype=torch.float32)
+        rows, ch = eng.prefix_out_shape([n1, n2])
+        t_next = torch.empty(rows, ch, device=dev, dtype=L.TORCH_DTYPE[DT_OF[model.precision]])
         pst.wait_event(fork)
         with torch.cuda.stream(pst):
-            n1 = lookahead["img1"]
-            n2 = second_view(n1, img2.shape[-1])
-            lookahead["img2"], lookahead["prefix"] = n2, eng.run_prefix([n1, n2])
-        for t_ in (n2, lookahead["prefix"]["t"]):           # allocated on the prefix stream, consumed on the caller's in the next step
-            t_.record_stream(main)
+            L.resize_planar_fwd(n1, n2, n1.shape[0] * n1.shape[1], n1.shape[2], n1.shape[3], n2.shape[2], n2.shape[3], True)
+            lookahead["img2"], lookahead["prefix"] = n2, eng.run_prefix([n1, n2], out=t_next)
     # Backward-only preparation — the transposed weight packs (420 MB of traffic) and the gradient memset (420 MB) — on a third
     # stream behind the forward pass: it runs while the loss phase's small kernels leave the chip's bandwidth idle.
     aux = _aux_stream(eng, dev) if use_streams else main
