@@ -223,7 +223,7 @@ def main():
             traffic_src = os.path.relpath(f, ROOT)
         except Exception:
             pass
-        roof = {"bound": "mfma", "kernel": "conv_igemm256_kernel + conv_igemm512x128_kernel + conv_igemm_kernel (every fwd / dgrad conv launch)", "achieved": round(achieved, 1), "peak": peak,
+        roof = {"bound": "mfma", "kernel": "conv_igemm256_kernel + conv_bwd_pair_kernel + conv_igemm512x128_kernel + conv_igemm_kernel (every fwd / dgrad conv launch; a dgrad launch that carries its layer's weight-gradient tiles counts their flops too)", "achieved": round(achieved, 1), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "launches_per_step": n_launch // a.steps, "event_samples": len(prof),
                 "avg_launch_ms": round(tot_ms / n_launch, 4), "avg_launch_gflop": round(tot_fl / n_launch / 1e9, 2),

@@ -103,6 +103,12 @@ typedef struct wseg_wgrad_desc {
   int32_t IH2, IW2, OH2, OW2;  /* optional second row segment, as in wseg_conv_desc (OH2 == 0: none) */
 } wseg_wgrad_desc;
 int wseg_conv_wgrad(const wseg_wgrad_desc* d, void* stream);
+/* A layer's data gradient (`dg`: mode 1) and a weight gradient (`wg`) as ONE launch: both depend only on dY (autograd runs them back to back:
+ * network/resnet38d.py:17-44 backward), and as one grid the weight-gradient tiles back-fill the data gradient's partly filled last round and the two
+ * kinds of tile do not end — and store — at the same time.  Qualifies: bf16, stride-1 single-source data gradient on the 256-tile kernel + a
+ * weight gradient on the 256 x 256 phase-pipelined kernel; anything else runs as the two ordinary launches, in that order.  Same results. */
+int wseg_conv_bwd_pair(const wseg_conv_desc* dg, const wseg_wgrad_desc* wg, void* stream);
+int wseg_conv_bwd_pair_fuses(const wseg_conv_desc* dg, const wseg_wgrad_desc* wg);   /* 1: one grid, 0: two launches, < 0: bad arguments (launches nothing) */
 
 /* ---- weight packing ----------------------------------------------------------------------
  * master f32 [OC][T][IC] -> fwd pack [OCp][T][ICp] and transposed pack [ICp][T][OCp] in `dtype`

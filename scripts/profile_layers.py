@@ -1,5 +1,6 @@
 """Per-layer time / TFLOP/s of the conv launches inside real training steps (HIP events)."""
 import sys, os, random, contextlib, io, collections
+os.environ.setdefault("WSEG_BWD_PAIR", "0")      # per-layer table: data gradients and weight gradients as separate launches (the product pairs them)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from wseg_amd import synth, _lib as L

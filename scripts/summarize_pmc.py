@@ -15,7 +15,7 @@ import csv
 import json
 import sys
 
-FAMILIES = [("conv_igemm256", "conv_igemm256"), ("conv_igemm512", "conv_igemm512"), ("conv_igemm_kernel", "conv_igemm128"), ("conv_wgrad", "conv_wgrad"),
+FAMILIES = [("conv_bwd_pair", "conv_bwd_pair"), ("conv_igemm256", "conv_igemm256"), ("conv_igemm512", "conv_igemm512"), ("conv_igemm_kernel", "conv_igemm128"), ("conv_wgrad", "conv_wgrad"),
             ("sgd_kernel", "sgd"), ("stem_kernel", "stem"), ("pcm_", "pcm"), ("nce_", "nce"), ("up_", "maps"),
             ("pack_tr", "pack"), ("to_bf16", "pack")]
 
@@ -52,7 +52,7 @@ def main():
             continue
         fb, wb = 2.0 * fa[fam][1] / max(1, fa[fam][0]), wa[fam][1] / max(1, wa[fam][0])
         res[fam] = {"launches": n, "fetch_bytes_per_launch_corrected": fb, "write_bytes_per_launch": wb, "hbm_bytes_per_launch": fb + wb}
-        if fam in ("conv_igemm256", "conv_igemm512", "conv_igemm128"):
+        if fam in ("conv_igemm256", "conv_igemm512", "conv_igemm128", "conv_bwd_pair"):       # (bench.py's roofline launches: fwd, dgrad, dgrad+wgrad grids)
             conv[0] += n; conv[1] += fb * n; conv[2] += wb * n
     if conv[0]:
         res["conv_igemm"] = {"launches": conv[0], "fetch_bytes_per_launch_corrected": conv[1] / conv[0],

@@ -292,6 +292,88 @@ def test_conv256_fwd_dgrad(case):
         np.testing.assert_allclose(dx7.float().cpu().numpy(), _nhwc(x.grad).numpy(), **tol)
 
 
+@pytest.mark.parametrize("geom", [(2, 132, 128, 256, 256, 3, 1, None), (2, 88, 100, 512, 256, 3, 2, None), (2, 96, 96, 512, 256, 1, 1, (36, 44)),
+                                  (1, 40, 40, 256, 256, 3, 1, None)])
+def test_conv_bwd_pair(geom):
+    """wseg_conv_bwd_pair: a layer's data gradient and weight gradient as ONE grid (dgrad tiles first, weight-gradient tiles behind them).  dX must be
+    bit-identical to the stand-alone data gradient (same tiles, same K order), dW equal to the stand-alone weight gradient up to the order of its float
+    atomics, both right against F.conv2d's backward.  Cases: 3x3, dilation 2 with IC != OC, 1x1 with two row segments (the training step's two views);
+    the last one is too small for the 256-tile kernel: the library must fall back to two launches."""
+    from wseg_amd import _lib as L
+    N, H, W, IC, OC, k, d, seg = geom
+    tdt, dev = torch.bfloat16, "cuda"
+    pad = d * (k // 2)
+    sizes = [(H, W)] + ([seg] if seg else [])
+    w = _rand((OC, IC, k, k), 2, (2.0 / (IC * k * k)) ** 0.5).to(tdt).float().requires_grad_(True)
+    xs = [_rand((N, IC, h_, w_), 10 + i).to(tdt).float().requires_grad_(True) for i, (h_, w_) in enumerate(sizes)]
+    dys = [_rand((N, OC, h_, w_), 20 + i).to(tdt).float() for i, (h_, w_) in enumerate(sizes)]
+    for x, dy in zip(xs, dys):
+        F.conv2d(x, w, None, 1, pad, d).backward(dy)
+    rows = lambda t: t.permute(0, 2, 3, 1).reshape(-1, t.shape[1])
+    xj = torch.cat([rows(x.detach()) for x in xs]).to(dev, tdt)
+    dyj = torch.cat([rows(dy) for dy in dys]).to(dev, tdt)
+    wt = torch.empty(IC, k * k, OC, device=dev, dtype=tdt)
+    L.pack_weights(w.detach().permute(0, 2, 3, 1).contiguous().to(dev), None, wt, OC, k * k, IC, OC, IC, L.dtype_code(wt))
+    seg2 = (seg[0], seg[1], seg[0], seg[1]) if seg else None
+    geo = dict(N=N, KH=k, KW=k, stride=1, dil=d, pad=pad, seg2=seg2)
+    wkw = dict(IH=H, IW=W, IC=IC, OH=H, OW=W, OC=OC, **geo)
+    dx_a = torch.full((xj.shape[0], IC), float("nan"), device=dev, dtype=tdt)
+    L.conv_igemm(dyj, wt, dx_a, IH=H, IW=W, IC=OC, OH=H, OW=W, OC=IC, mode=1, **geo)
+    dw_a = torch.zeros(OC, k * k, IC, device=dev, dtype=torch.float32)
+    L.conv_wgrad(xj, dyj, dw_a, **wkw)
+    dx_b = torch.full_like(dx_a, float("nan"))
+    dw_b = torch.zeros_like(dw_a)
+    L.TRACK_PAIRS = True
+    try:
+        L.conv_igemm(dyj, wt, dx_b, IH=H, IW=W, IC=OC, OH=H, OW=W, OC=IC, mode=1, pair_wgrad=(xj, dyj, dw_b, wkw), **geo)
+        fused = L.LAST_PAIR_FUSED
+    finally:
+        L.TRACK_PAIRS = False
+    assert fused == (0 if H == 40 else 1)
+    assert torch.equal(dx_a, dx_b)
+    ref_dx = torch.cat([rows(x.grad) for x in xs]).numpy()
+    np.testing.assert_allclose(dx_b.float().cpu().numpy(), ref_dx, rtol=2e-2, atol=2e-2)
+    ref_dw = w.grad.permute(0, 2, 3, 1).reshape(OC, k * k, IC).numpy()
+    scale = np.abs(ref_dw).max()
+    assert np.abs(dw_b.cpu().numpy() - ref_dw).max() / scale < 1e-2
+    assert float((dw_a - dw_b).abs().max()) / scale < 1e-4
+
+
+def test_conv_bwd_pair_two_sources():
+    """The joint grid with a two-source data gradient (a bottleneck block's `D . W_branch1 + du1 . W_branch2a`, mode 1, BN-ReLU-backward epilogue with a
+    mask) and the skip conv's weight gradient: bit-identical dX to the stand-alone two-source launch, dW to the order of the atomics."""
+    from wseg_amd import _lib as L
+    tdt, dev = torch.bfloat16, "cuda"
+    N, H, W, C1, C2, OCd = 2, 96, 100, 512, 128, 256           # D [M, 512], du1 [M, 128] -> d_t [M, 256]; weight gradient of the 256 -> 512 skip conv
+    M = N * H * W
+    D = _rand((M, C1), 1).to(dev, tdt)
+    du1 = _rand((M, C2), 2).to(dev, tdt)
+    t = _rand((M, OCd), 3).to(dev, tdt)
+    mask = (_rand((M, OCd), 4) > 0).to(dev, tdt)
+    wcat = _rand((OCd, 1, C1 + C2), 5, (1.0 / (C1 + C2)) ** 0.5).to(dev, tdt)
+    scale = (_rand((OCd,), 6) + 1.5).to(dev)
+    kw = dict(N=N, IH=H, IW=W, IC=C1, OH=H, OW=W, OC=OCd, KH=1, KW=1, mode=1, in2=du1, IC2=C2, epi=1, scale=scale, mask=mask)
+    wkw = dict(N=N, IH=H, IW=W, IC=OCd, OH=H, OW=W, OC=C1, KH=1, KW=1)
+    dx_a = torch.full((M, OCd), float("nan"), device=dev, dtype=tdt)
+    L.conv_igemm(D, wcat, dx_a, **kw)
+    dw_a = torch.zeros(C1, 1, OCd, device=dev, dtype=torch.float32)
+    L.conv_wgrad(t, D, dw_a, **wkw)
+    dx_b, dw_b = torch.full_like(dx_a, float("nan")), torch.zeros_like(dw_a)
+    L.TRACK_PAIRS = True
+    try:
+        L.conv_igemm(D, wcat, dx_b, pair_wgrad=(t, D, dw_b, wkw), **kw)
+        assert L.LAST_PAIR_FUSED == 1
+    finally:
+        L.TRACK_PAIRS = False
+    assert torch.equal(dx_a, dx_b) and torch.isfinite(dx_b.float()).all()
+    ref = (D.float() @ wcat[:, 0, :C1].float().t() + du1.float() @ wcat[:, 0, C1:].float().t()) * scale * (mask.float() != 0)
+    np.testing.assert_allclose(dx_b.float().cpu().numpy(), ref.cpu().numpy(), rtol=2e-2, atol=3e-2)
+    ref_dw = (D.float().t() @ t.float()).cpu().numpy()
+    sc = np.abs(ref_dw).max()
+    assert np.abs(dw_b[:, 0].cpu().numpy() - ref_dw).max() / sc < 1e-2
+    assert float((dw_a - dw_b).abs().max()) / sc < 1e-4
+
+
 @pytest.mark.parametrize("case", CASES256)
 def test_conv256_split_bf16(case):
     """The 256-tile kernel on f32 storage with split-bf16 products (dtype WSEG_F32X3): forward with the fused BN-ReLU second output

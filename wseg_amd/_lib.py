@@ -97,10 +97,15 @@ def dtype_code(t):
     raise TypeError(f"unsupported dtype {t.dtype}")
 
 
+TRACK_PAIRS, LAST_PAIR_FUSED = False, None        # tests: whether the last pair_wgrad launch was ONE grid
+
+
 def conv_igemm(inp, w, out=None, out2=None, *, N, IH, IW, IC, OH, OW, OC, KH, KW, stride=1, dil=1, pad=0,
                mode=0, epi=0, r_pre=None, r_post=None, mask=None, scale=None, shift=None, drop=None,
                ld_in=None, ld_out=None, ld_out2=None, ld_rpre=None, ld_rpost=None, ld_mask=None, relu_out2=1,
-               relu_lt=0, bm_hint=0, seg2=None, in2=None, ld_in2=None, IC2=0, dtype=None):
+               relu_lt=0, bm_hint=0, seg2=None, in2=None, ld_in2=None, IC2=0, dtype=None, pair_wgrad=None):
+    """pair_wgrad: (x, dy, dw, kwargs of conv_wgrad) — a weight gradient launched in the SAME grid as this data gradient (wseg_conv_bwd_pair; the
+    library falls back to two launches when the pair does not qualify)."""
     d = ConvDesc()
     d.inp, d.w, d.out, d.out2 = _ptr(inp), _ptr(w), _ptr(out), _ptr(out2)
     d.r_pre, d.r_post, d.mask = _ptr(r_pre), _ptr(r_post), _ptr(mask)
@@ -121,19 +126,29 @@ def conv_igemm(inp, w, out=None, out2=None, *, N, IH, IW, IC, OH, OW, OC, KH, KW
     if sampled:                                  # bench.py: HIP events on the launch stream around this launch
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    check(lib.wseg_conv_igemm(C.byref(d), C.c_void_p(stream_ptr())), "wseg_conv_igemm")
+    wflops = 0.0
+    if pair_wgrad is not None:
+        wx, wdy, wdw, wkw = pair_wgrad
+        wd = _wgrad_desc(wx, wdy, wdw, **wkw)
+        global LAST_PAIR_FUSED
+        LAST_PAIR_FUSED = lib.wseg_conv_bwd_pair_fuses(C.byref(d), C.byref(wd)) if TRACK_PAIRS else None
+        check(lib.wseg_conv_bwd_pair(C.byref(d), C.byref(wd), C.c_void_p(stream_ptr())), "wseg_conv_bwd_pair")
+        wpix = wkw["N"] * wkw["OH"] * wkw["OW"] + (wkw["N"] * wkw["seg2"][2] * wkw["seg2"][3] if wkw.get("seg2") is not None else 0)
+        wflops = 2.0 * wpix * wkw["IC"] * wkw["OC"] * wkw["KH"] * wkw["KW"]
+    else:
+        check(lib.wseg_conv_igemm(C.byref(d), C.c_void_p(stream_ptr())), "wseg_conv_igemm")
     if sampled:
         ev1.record()
         pix = N * (OH * OW if mode == 0 else IH * IW)        # algorithmic: the conv's output pixels
         if seg2 is not None:
             pix += N * (seg2[2] * seg2[3] if mode == 0 else seg2[0] * seg2[1])
         kin = IC * KH * KW + ((IC2 or IC) if in2 is not None else 0)
-        PROFILE.append((ev0, ev1, 2.0 * pix * kin * OC,
-                        f"{'fwd' if mode == 0 else 'dgrad'} {IC}{('+%d' % (IC2 or IC)) if in2 is not None else ''}->{OC} k{KH} s{stride} d{dil} {OH}x{OW}", launch_idx))
+        PROFILE.append((ev0, ev1, 2.0 * pix * kin * OC + wflops,
+                        f"{'fwd' if mode == 0 else ('dgrad+wgrad' if pair_wgrad is not None else 'dgrad')} {IC}{('+%d' % (IC2 or IC)) if in2 is not None else ''}->{OC} k{KH} s{stride} d{dil} {OH}x{OW}", launch_idx))
 
 
-def conv_wgrad(x, dy, dw, *, N, IH, IW, IC, OH, OW, OC, KH, KW, stride=1, dil=1, pad=0,
-               ld_x=None, ld_dy=None, split_k=0, IC_dw=None, OC_dw=None, tile_hint=0, seg2=None, dtype=None):
+def _wgrad_desc(x, dy, dw, *, N, IH, IW, IC, OH, OW, OC, KH, KW, stride=1, dil=1, pad=0,
+                ld_x=None, ld_dy=None, split_k=0, IC_dw=None, OC_dw=None, tile_hint=0, seg2=None, dtype=None):
     d = WgradDesc()
     d.x, d.dy, d.dw = _ptr(x), _ptr(dy), _ptr(dw)
     d.N, d.IH, d.IW, d.IC, d.ld_x = N, IH, IW, IC, ld_x or IC
@@ -143,6 +158,14 @@ def conv_wgrad(x, dy, dw, *, N, IH, IW, IC, OH, OW, OC, KH, KW, stride=1, dil=1,
     d.IC_dw, d.OC_dw, d.tile_hint = IC_dw or IC, OC_dw or OC, tile_hint
     if seg2 is not None:
         d.IH2, d.IW2, d.OH2, d.OW2 = seg2
+    assert dw.dtype == torch.float32
+    return d
+
+
+def conv_wgrad(x, dy, dw, *, N, IH, IW, IC, OH, OW, OC, KH, KW, stride=1, dil=1, pad=0,
+               ld_x=None, ld_dy=None, split_k=0, IC_dw=None, OC_dw=None, tile_hint=0, seg2=None, dtype=None):
+    d = _wgrad_desc(x, dy, dw, N=N, IH=IH, IW=IW, IC=IC, OH=OH, OW=OW, OC=OC, KH=KH, KW=KW, stride=stride, dil=dil, pad=pad, ld_x=ld_x, ld_dy=ld_dy,
+                    split_k=split_k, IC_dw=IC_dw, OC_dw=OC_dw, tile_hint=tile_hint, seg2=seg2, dtype=dtype)
     assert dw.dtype == torch.float32
     if PROFILE_WGRAD is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -12,7 +12,7 @@ mkdir -p _obj
 pids=()
 for f in $SRCS; do
   o=_obj/${f%.hip}.o
-  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$(cat _obj/.flags 2>/dev/null)" != "$FLAGS" ] || [ common.h -nt "$o" ] || [ ../../include/wseg_hip.h -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ conv_wgrad_kernels.h -nt "$o" ] || [ "$(cat _obj/.flags 2>/dev/null)" != "$FLAGS" ] || [ common.h -nt "$o" ] || [ ../../include/wseg_hip.h -nt "$o" ]; then
     hipcc $FLAGS -c "$f" -o "$o" &
     pids+=($!)
   fi

@@ -13,6 +13,7 @@
 #include <stdlib.h>
 #include <algorithm>
 #include "common.h"
+#include "conv_wgrad_kernels.h"   // (wseg_wg::…: the weight-gradient tile body and its host-side plan, for wseg_conv_bwd_pair)
 
 #ifdef WSEG_PROBES   // timing diagnostics of probe builds: bm_hint -1 / -2 feed A / B from the zero page (results wrong by design)
 #define WSEG_DIAG_ZERO_A(d) ((d).bm_hint == -1)
@@ -564,17 +565,18 @@ constexpr int HALF256 = 16384, TILE256 = 4 * HALF256;
 // DT = WSEG_F32X3 (split-bf16 products on f32 storage): the same pipeline on f32 activation rows (32 channels per 128-B K-tile row,
 // split into hi + lo at fragment-read time) and the pre-split weight pack [32 hi | 32 lo]; the two fragment sets af[0] / af[1] and
 // b[0] / b[1] that hold the two K halves in bf16 mode hold (hi, lo) here, and a quadrant issues lo.hi + hi.lo + hi.hi.
+// The tile body is a device function of (arguments, the workgroup's 128 KiB LDS buffer, block id): `conv_igemm256_kernel` is one workgroup = one
+// tile; `conv_bwd_pair_kernel` (below) runs it in the first workgroups of a grid whose other workgroups run the weight-gradient tile body.
 template <int EPI, int STG, int NI = 8, int DT = WSEG_BF16>
-__global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const Args a) {
+__device__ __forceinline__ void conv_igemm256_tile(const Args& a, char* smem, const int bid) {
   constexpr bool X3 = DT == WSEG_F32X3;
   constexpr int ES = X3 ? 4 : 2, CH = 16 / ES;
   constexpr int RH = NI * 16, BMT = 2 * RH;        // rows per wave row / per tile
   static_assert(NI == 8 || (NI == 7 && STG >= 2), "224-row tiles exist for the 2-phase schedules only");
-  __shared__ __attribute__((aligned(16))) char smem[2 * TILE256];
   const wseg_conv_desc& d = a.d;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tile = xcd_remap(blockIdx.x, a.nwg);
+  const int tile = xcd_remap(bid, a.nwg);
   const int tm = tile / a.ntn, tn = tile - tm * a.ntn;
   const int m0 = a.row0 + tm * BMT, n0 = tn * 256;
   const int wr = wid >> 2, wc = wid & 3;
@@ -840,6 +842,13 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const Args a) {
   __syncthreads();                                 // every wave is done with the pipeline buffers
   wave_local_epilogue<EPI, NI, DT>(a, smem, wid, lane, m0 + wr * RH, wc * 64, n0, acc);
 }
+
+template <int EPI, int STG, int NI = 8, int DT = WSEG_BF16>
+__global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const Args a) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * TILE256];
+  conv_igemm256_tile<EPI, STG, NI, DT>(a, smem, blockIdx.x);
+}
+
 
 
 #ifdef WSEG_PROBES   // measured dead end, kept for A/B runs only: built by `WSEG_PROBES=1 bash build.sh`
@@ -1173,9 +1182,25 @@ __global__ __launch_bounds__(512, 2) void conv_igemm512x128_kernel(const Args a)
   wave_local_epilogue<EPI, 8>(a, smem, wid, lane, m0 + wr * 128, wc * 64, n0, acc);
 }
 
+// ---- A layer's data gradient and weight gradient as ONE grid.  Both need only dY; as two kernels on a stream each pays its own partly filled
+// last round and its own synchronised epilogue burst (all CUs store at once while the matrix pipes idle).  Here the first `nd_pad` workgroups run the
+// 256-tile dgrad body and the others the 256 x 256 weight-gradient body (same 512-thread / 128 KiB shape): the grid order back-fills the dgrad tail with
+// wgrad tiles and the two kinds of tile end at different times.  nd_pad is a multiple of 8, so block id % 8 (the XCD) is the same for both bodies' maps.
+template <int EPI, int NI, int UNIT>
+__global__ __launch_bounds__(512, 2) void conv_bwd_pair_kernel(const Args ad, const wseg_wg::Args aw, const int nd_pad) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * TILE256];
+  static_assert(2 * TILE256 == 2 * 4 * 16384, "both tile bodies use the same 128 KiB");
+  const int b = blockIdx.x;
+  if (b < nd_pad) {
+    if (b < ad.nwg) conv_igemm256_tile<EPI, 2, NI, WSEG_BF16>(ad, smem, b);
+  } else {
+    wseg_wg::conv_wgrad_pipe_tile<2, UNIT>(aw, smem, b - nd_pad);
+  }
+}
+
 }  // namespace
 
-extern "C" int wseg_conv_igemm(const wseg_conv_desc* d, void* stream) {
+static int conv_validate(const wseg_conv_desc* d) {
   WSEG_CHECK(d && d->in && d->w && (d->out || d->out2), "conv_igemm: null pointer");
   WSEG_CHECK(d->dtype == WSEG_F32 || d->dtype == WSEG_BF16 || d->dtype == WSEG_F32X3, "conv_igemm: bad dtype %d", d->dtype);
   const int es = d->dtype == WSEG_BF16 ? 2 : 4;
@@ -1194,6 +1219,27 @@ extern "C" int wseg_conv_igemm(const wseg_conv_desc* d, void* stream) {
   const long M = (long)d->N * d->OH * d->OW + (long)d->N * d->OH2 * d->OW2;
   WSEG_CHECK(d->OH2 >= 0 && (d->OH2 == 0 || (d->OW2 > 0 && d->IH2 > 0 && d->IW2 > 0)), "conv_igemm: bad second segment");
   WSEG_CHECK(M < (1L << 31) && (long)d->N * d->IH * d->IW * d->ld_in < (1L << 40), "conv_igemm: tensor too large");
+  return 0;
+}
+
+// tile choice of the bf16 256-tile kernel (default switches): by CU time in units of (32 rows x 256 columns x K) at the 256-tile kernel's rate — a
+// round of NI-block tiles costs NI, a round of the 128^2 kernel (two resident workgroups of 2 units each, 0.75 of that rate) 5.33
+static bool conv_cost_prefers_256(long M, int OC) {
+  const long t256 = ((M + 255) / 256) * ((OC + 255) / 256);
+  const long rounds = (t256 + 255) / 256;
+  const long t224 = ((M + 223) / 224) * ((OC + 255) / 256), t128 = ((M + 127) / 128) * ((OC + 127) / 128);
+  const double c_big = std::min((double)rounds * 8.0, (double)((t224 + 255) / 256) * 7.0), c_128 = (double)((t128 + 511) / 512) * 5.33;
+  return c_big <= c_128;
+}
+static bool conv_rounds_prefer_224(long M, int ntn256) {
+  const long t8 = ((M + 255) / 256) * ntn256, t7 = ((M + 223) / 224) * ntn256;
+  return ((t7 + 255) / 256) * 7 < ((t8 + 255) / 256) * 8;
+}
+
+extern "C" int wseg_conv_igemm(const wseg_conv_desc* d, void* stream) {
+  if (int rc = conv_validate(d)) return rc;
+  const int es = d->dtype == WSEG_BF16 ? 2 : 4;
+  const long M = (long)d->N * d->OH * d->OW + (long)d->N * d->OH2 * d->OW2;
   Args a;
   a.d = *d;
   a.perm = 0; a.Q1 = a.Q2 = 0;
@@ -1364,6 +1410,74 @@ extern "C" int wseg_conv_igemm(const wseg_conv_desc* d, void* stream) {
   }
 #undef WSEG_LAUNCH_CONV1
 #undef WSEG_LAUNCH_CONV
+  WSEG_LAUNCH_CHECK();
+  return 0;
+}
+
+// One launch for `dg` (a stride-1 bf16 data gradient on the 256-tile kernel) and `wg` (a bf16 weight gradient on the 256 x 256 phase-pipelined
+// kernel) when both qualify; otherwise the two ordinary launches, in that order.  Results are those of the separate launches.
+// 1: the pair qualifies for the joint grid (pl then holds the weight gradient's plan), 0: two launches, < 0: error
+static int conv_bwd_pair_plan(const wseg_conv_desc* dg, const wseg_wgrad_desc* wg, wseg_wg::Plan& pl) {
+  WSEG_CHECK(dg && wg, "conv_bwd_pair: null descriptor");
+  static const int pair_ok = getenv("WSEG_BWD_PAIR") ? atoi(getenv("WSEG_BWD_PAIR")) : 1;           // (0: A/B switch — two launches)
+  static const int stagger = getenv("WSEG_CONV_STAGGER") ? atoi(getenv("WSEG_CONV_STAGGER")) : 2;
+  static const int auto256 = getenv("WSEG_CONV256") ? atoi(getenv("WSEG_CONV256")) : 1;
+  static const int auto224 = getenv("WSEG_CONV224") ? atoi(getenv("WSEG_CONV224")) : 1;
+  const long M = (long)dg->N * dg->OH * dg->OW + (long)dg->N * dg->OH2 * dg->OW2;
+  const bool ok = pair_ok && stagger == 2 && auto256 == 1 && auto224 == 1 && dg->dtype == WSEG_BF16 && wg->dtype == WSEG_BF16 && dg->mode == 1 &&
+                  dg->stride == 1 && dg->bm_hint == 0 && dg->OC % 256 == 0 && dg->out != nullptr && dg->out2 == nullptr &&
+                  dg->epi >= 0 && dg->epi <= 2 && (dg->in2 != nullptr || conv_cost_prefers_256(M, dg->OC)) &&      // (two sources: always the 256-tile kernel)
+                  (dg->in2 == nullptr || (dg->KH == dg->KW && (dg->KH & 1) && dg->KH * dg->KW < 15 && dg->pad == dg->dil * (dg->KH / 2) && dg->ld_in2 % 8 == 0 &&
+                                          (((dg->IC2 > 0 ? dg->IC2 : dg->IC) * 2) % ROWB) == 0 && dg->ld_in2 >= (dg->IC2 > 0 ? dg->IC2 : dg->IC)));
+  if (!ok) return 0;
+  if (int rc = wseg_wg::wgrad_plan(wg, pl)) return rc;
+  return (pl.kind == 0 && pl.a.stagger == 2) ? 1 : 0;
+}
+extern "C" int wseg_conv_bwd_pair_fuses(const wseg_conv_desc* dg, const wseg_wgrad_desc* wg) {
+  wseg_wg::Plan pl;
+  return conv_bwd_pair_plan(dg, wg, pl);
+}
+
+extern "C" int wseg_conv_bwd_pair(const wseg_conv_desc* dg, const wseg_wgrad_desc* wg, void* stream) {
+  wseg_wg::Plan pl;
+  const int fuse = conv_bwd_pair_plan(dg, wg, pl);
+  if (fuse < 0) return fuse;
+  const bool ok = fuse == 1;
+  const long M = (long)dg->N * dg->OH * dg->OW + (long)dg->N * dg->OH2 * dg->OW2;
+  if (!ok) {
+    if (int rc = wseg_conv_igemm(dg, stream)) return rc;
+    return wseg_conv_wgrad(wg, stream);
+  }
+  if (int rc = conv_validate(dg)) return rc;
+  WSEG_CHECK(dg->IH <= 16384 && dg->IW <= 16384 && dg->OH <= 16384 && dg->OW <= 16384 && dg->pad <= 4096 &&
+             (long)dg->N * dg->IH * dg->IW + (long)dg->N * dg->IH2 * dg->IW2 < (1L << 31), "conv_bwd_pair: shape too large for the 256-tile kernel");
+  Args a;
+  a.d = *dg;
+  a.perm = 0; a.Q1 = a.Q2 = 0;
+  static const int early_b = getenv("WSEG_CONV_EARLYB") ? atoi(getenv("WSEG_CONV_EARLYB")) : 1;
+  a.early_b = early_b;
+  a.M = (int)M;
+  const int ic2 = dg->in2 ? (dg->IC2 > 0 ? dg->IC2 : dg->IC) : 0;       // two sources: the second one is an extra last "tap" (as in wseg_conv_igemm)
+  a.taps = dg->KH * dg->KW + (dg->in2 ? 1 : 0);
+  a.cpt = dg->IC * 2 / ROWB;
+  a.cpt2 = ic2 * 2 / ROWB;
+  a.krow = dg->KH * dg->KW * dg->IC + ic2;
+  a.ntn = (dg->OC + 255) / 256;
+  a.row0 = 0;
+  const bool ni7 = conv_rounds_prefer_224(M, a.ntn);
+  const int bmt = ni7 ? 224 : 256;
+  a.nwg = (int)(((M + bmt - 1) / bmt) * a.ntn);
+  const int nd_pad = (a.nwg + 7) & ~7;
+  const dim3 grid((unsigned)(nd_pad + pl.a.nwg));
+  hipStream_t s = (hipStream_t)stream;
+#define WSEG_LAUNCH_PAIR(EPI_, NI_)                                                                                              \
+  do {                                                                                                                           \
+    if (pl.unit) hipLaunchKernelGGL((conv_bwd_pair_kernel<EPI_, NI_, 1>), grid, dim3(512), 0, s, a, pl.a, nd_pad);               \
+    else hipLaunchKernelGGL((conv_bwd_pair_kernel<EPI_, NI_, 0>), grid, dim3(512), 0, s, a, pl.a, nd_pad);                       \
+  } while (0)
+  if (ni7) { if (dg->epi == 0) WSEG_LAUNCH_PAIR(0, 7); else if (dg->epi == 1) WSEG_LAUNCH_PAIR(1, 7); else WSEG_LAUNCH_PAIR(2, 7); }
+  else { if (dg->epi == 0) WSEG_LAUNCH_PAIR(0, 8); else if (dg->epi == 1) WSEG_LAUNCH_PAIR(1, 8); else WSEG_LAUNCH_PAIR(2, 8); }
+#undef WSEG_LAUNCH_PAIR
   WSEG_LAUNCH_CHECK();
   return 0;
 }

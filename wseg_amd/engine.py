@@ -726,11 +726,28 @@ class Engine:
                     pcm_join[0] = None
                 self.block_done_hook(nm)
 
-        def dgrad(dy, wname, out, conv_cin, conv_cout, k, stride, dil, din, dout, **kw):
+        def pair_args(pair):
+            """`pair_wgrad` of L.conv_igemm for the weight gradient (name, x, dy, cin, cout, k, stride, dil, din, dout), or None (then the caller
+            launches it on its own): bf16 mode, no separate weight-gradient stream"""
+            if pair is None:
+                return None
+            pnm, px, pdy, pcin, pcout, pk, pstride, pdil, pdin, pdout = pair
+            if not (dt == L.BF16 and wstream is None and trainable(pnm)):
+                return None
+            off, n = self.offsets[pnm]
+            return (px, pdy, self.flat_g[off:off + n],
+                    dict(N=N, IH=pdin[0][0], IW=pdin[0][1], IC=pcin, OH=pdout[0][0], OW=pdout[0][1], OC=pcout, KH=pk, KW=pk, stride=pstride,
+                         dil=pdil, pad=pdil * (pk // 2), seg2=seg(pdin, pdout), dtype=_cdt(dt)))
+
+        def dgrad(dy, wname, out, conv_cin, conv_cout, k, stride, dil, din, dout, pair=None, **kw):
             # in = dY over the conv's OUTPUT dims (dout), out = dX over its INPUT dims (din)
+            # pair = (name, x, dy, cin, cout, k, stride, dil, din, dout): a weight gradient of the same dY, launched in the same grid (bf16 mode)
             seg2 = (dout[1][0], dout[1][1], din[1][0], din[1][1]) if V == 2 else None
+            pw = pair_args(pair)
             L.conv_igemm(dy, P["wt"][wname], out, None, N=N, IH=dout[0][0], IW=dout[0][1], IC=conv_cout, OH=din[0][0], OW=din[0][1],
-                         OC=conv_cin, KH=k, KW=k, stride=stride, dil=dil, pad=dil * (k // 2), mode=1, seg2=seg2, dtype=_cdt(dt), **kw)
+                         OC=conv_cin, KH=k, KW=k, stride=stride, dil=dil, pad=dil * (k // 2), mode=1, seg2=seg2, dtype=_cdt(dt), pair_wgrad=pw, **kw)
+            if pair is not None and pw is None:
+                wgrad(*pair)
 
         # ---- per-view adjoints of the x8 upsamples / gather of the stride-8 gradients
         d_cam_low, d_rvd = [], []
@@ -825,21 +842,27 @@ class Engine:
             if kind == "res":
                 s1, _ = P["bn"][name + ".bn_branch2b1"]
                 du = E(Mo, mid)
-                dgrad(D, name + ".conv_branch2b1", du, mid, cout, 3, 1, d, dout, dout, epi=1, scale=s1, mask=sv["v"])
-                wgrad(name + ".conv_branch2b1", sv["v"], D, mid, cout, 3, 1, d, dout, dout)
-                wgrad(name + ".conv_branch2a", sv["t"], du, cin, mid, 3, stride, fd, din, dout)
-                if not same:
-                    wgrad(name + ".conv_branch1", sv["t"], D, cin, cout, 1, stride, 1, din, dout)
+                # (each data gradient takes the weight gradient of the same dY into its launch: wseg_conv_bwd_pair)
+                dgrad(D, name + ".conv_branch2b1", du, mid, cout, 3, 1, d, dout, dout, epi=1, scale=s1, mask=sv["v"],
+                      pair=(name + ".conv_branch2b1", sv["v"], D, mid, cout, 3, 1, d, dout, dout))
+                pair2a = (name + ".conv_branch2a", sv["t"], du, cin, mid, 3, stride, fd, din, dout)
+                if not (same and not first_trainable):
+                    wgrad(*pair2a)
+                pair1 = (name + ".conv_branch1", sv["t"], D, cin, cout, 1, stride, 1, din, dout)
+                fused_skip = (name + ".skip_fused") in P["wt"] and not first_trainable
+                if not same and not (fused_skip and pair_args(pair1) is not None):
+                    wgrad(*pair1)
                 if first_trainable:
                     block_done(name)
                     break
                 Din = E(Mi, cin)
                 if same:
-                    dgrad(du, name + ".conv_branch2a", Din, cin, mid, 3, stride, fd, din, dout, epi=1, scale=sa, mask=sv["t"], r_post=D)
+                    dgrad(du, name + ".conv_branch2a", Din, cin, mid, 3, stride, fd, din, dout, epi=1, scale=sa, mask=sv["t"], r_post=D, pair=pair2a)
                 elif (name + ".skip_fused") in P["wt"]:        # both data gradients into t: 9 taps of du + one K segment of D
                     seg2 = (dout[1][0], dout[1][1], din[1][0], din[1][1]) if V == 2 else None
                     L.conv_igemm(du, P["wt"][name + ".skip_fused"], Din, None, N=N, IH=dout[0][0], IW=dout[0][1], IC=mid, OH=din[0][0], OW=din[0][1],
-                                 OC=cin, KH=3, KW=3, stride=1, dil=fd, pad=fd, mode=1, in2=D, IC2=cout, epi=1, scale=sa, mask=sv["t"], seg2=seg2)
+                                 OC=cin, KH=3, KW=3, stride=1, dil=fd, pad=fd, mode=1, in2=D, IC2=cout, epi=1, scale=sa, mask=sv["t"], seg2=seg2,
+                                 pair_wgrad=pair_args(pair1))        # (+ the skip conv's weight gradient: same D)
                 else:
                     tmp = E(Mi, cin)
                     dgrad(D, name + ".conv_branch1", tmp, cin, cout, 1, stride, 1, din, dout)
@@ -853,21 +876,20 @@ class Engine:
                 d1 = masks[name + ".dropout_2b1"] if masks else None
                 d2 = masks[name + ".dropout_2b2"] if masks else None
                 du2 = E(Mo, c2)
-                dgrad(D, name + ".conv_branch2b2", du2, c2, cout, 1, 1, 1, dout, dout, epi=1, scale=s2, drop=d2, mask=sv["v2"])
-                wgrad(name + ".conv_branch2b2", sv["v2"], D, c2, cout, 1, 1, 1, dout, dout)
+                dgrad(D, name + ".conv_branch2b2", du2, c2, cout, 1, 1, 1, dout, dout, epi=1, scale=s2, drop=d2, mask=sv["v2"],
+                      pair=(name + ".conv_branch2b2", sv["v2"], D, c2, cout, 1, 1, 1, dout, dout))
                 du1 = E(Mo, c4)
-                dgrad(du2, name + ".conv_branch2b1", du1, c4, c2, 3, 1, d, dout, dout, epi=1, scale=s1, drop=d1, mask=sv["v1"])
-                wgrad(name + ".conv_branch2b1", sv["v1"], du2, c4, c2, 3, 1, d, dout, dout)
-                wgrad(name + ".conv_branch1", sv["t"], D, cin, cout, 1, stride, 1, din, dout)
+                dgrad(du2, name + ".conv_branch2b1", du1, c4, c2, 3, 1, d, dout, dout, epi=1, scale=s1, drop=d1, mask=sv["v1"],
+                      pair=(name + ".conv_branch2b1", sv["v1"], du2, c4, c2, 3, 1, d, dout, dout))
                 wgrad(name + ".conv_branch2a", sv["t"], du1, cin, c4, 1, stride, 1, din, dout)
                 Din = E(Mi, cin)
-                if (name + ".skip_fused") in P["wt"]:          # both 1x1 data gradients into t as ONE two-source product
-                    seg2 = (dout[1][0], dout[1][1], din[1][0], din[1][1]) if V == 2 else None
-                    L.conv_igemm(D, P["wt"][name + ".skip_fused"], Din, None, N=N, IH=dout[0][0], IW=dout[0][1], IC=cout, OH=din[0][0], OW=din[0][1],
-                                 OC=cin, KH=1, KW=1, in2=du1, IC2=c4, epi=1, scale=sa, mask=sv["t"], seg2=seg2)
+                if (name + ".skip_fused") in P["wt"]:          # both 1x1 data gradients into t as ONE two-source product (+ the skip conv's weight gradient)
+                    dgrad(D, name + ".skip_fused", Din, cin, cout, 1, 1, 1, din, dout, epi=1, scale=sa, mask=sv["t"], in2=du1, IC2=c4,
+                          pair=(name + ".conv_branch1", sv["t"], D, cin, cout, 1, stride, 1, din, dout))
                 else:
                     tmp = E(Mi, cin)
-                    dgrad(D, name + ".conv_branch1", tmp, cin, cout, 1, stride, 1, din, dout)
+                    dgrad(D, name + ".conv_branch1", tmp, cin, cout, 1, stride, 1, din, dout,
+                          pair=(name + ".conv_branch1", sv["t"], D, cin, cout, 1, stride, 1, din, dout))
                     dgrad(du1, name + ".conv_branch2a", Din, cin, c4, 1, stride, 1, din, dout, epi=1, scale=sa, mask=sv["t"], r_pre=tmp)
                 D = Din
                 block_done(name)
