@@ -770,11 +770,11 @@ class Engine:
             d_cam_low.append(dc)
             d_rvd.append(dr)
         # ---- PCM branch -> f9, f8_3, f8_4.  It ends in WEIGHT gradients only (f8_3 / f8_4 read conv4 / conv5 detached, resnet38_contrast.py:63-64),
-        # so nothing of the backbone's backward pass waits for it: WSEG_PCM_STREAM=1 runs it on its own stream beside the first blocks (0.5 ms of small
-        # kernels + two PCM launches that otherwise sit in front of the head's data gradient), joined before the gradients are consumed.
+        # so nothing of the backbone's backward pass waits for it: it runs on its own stream beside the first blocks (0.5 ms of small kernels + two PCM
+        # launches that otherwise sit in front of the head's data gradient), joined before the gradients are consumed (WSEG_PCM_STREAM=0: in line).
         pcm_stream = None
         if any(d is not None for d in d_rvd):
-            if os.environ.get("WSEG_PCM_STREAM", "0") == "1":   # (measured: -0.1..0.3 ms per step, but the conv launches it overlaps slow down: off by default)
+            if os.environ.get("WSEG_PCM_STREAM", "1") != "0":   # (same-box A/B: 35.25 / 35.16 -> 34.94 / 34.94 ms per step; the b7 launches it overlaps slow down by ~1 %)
                 pcm_stream = getattr(self, "_pcm_stream", None)
                 if pcm_stream is None or pcm_stream.device != dev:
                     pcm_stream = self._pcm_stream = torch.cuda.Stream(dev)
