@@ -7,4 +7,4 @@ timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/tr" -o r
 python "$ROOT/scripts/step_breakdown.py" $(find "$OUT/tr" -name run_kernel_trace.csv) 4 > "$OUT/breakdown.txt" 2>&1 &&
 python "$ROOT/scripts/step_timeline.py" $(find "$OUT/tr" -name run_kernel_trace.csv) > "$OUT/timeline.txt" 2>&1; echo "rc=$?"
 rm -rf "$OUT/tr"
-head -4 "$OUT/breakdown.txt"
+head -12 "$OUT/breakdown.txt"; grep "conv/wgrad launches" "$OUT/timeline.txt"

@@ -30,7 +30,7 @@ print(f"steps analysed: {nlast}; wall {wall/1e6:.3f} ms/step; sum of kernel dura
 q = collections.Counter()
 for r in seg: q[r.get("Queue_Id", "?")] += r["e"] - r["s"]
 print("per queue busy ms/step:", {k: round(v / nlast / 1e6, 3) for k, v in q.items()})
-groups = collections.OrderedDict([("conv fwd/dgrad", ("conv_igemm",)), ("wgrad", ("conv_wgrad",)), ("copies/fills (rocclr)", ("__amd_rocclr",)), ("torch elementwise etc.", ("at::",))])
+groups = collections.OrderedDict([("conv fwd / dgrad (+ paired wgrad)", ("conv_igemm", "conv_bwd_pair")), ("wgrad alone", ("conv_wgrad", "wseg_wg::conv_wgrad")), ("copies/fills (rocclr)", ("__amd_rocclr",)), ("torch elementwise etc.", ("at::",))])
 gs = collections.Counter()
 for k, (c, t) in agg.items():
     g = next((g for g, pats in groups.items() if any(k.startswith(p) for p in pats)), "other hand-written")

@@ -17,7 +17,7 @@ run = None
 prev_end = t0
 for r in seg:
     k = short(r["Kernel_Name"])
-    heavy = k.startswith("conv_igemm") or k.startswith("conv_wgrad")
+    heavy = k.startswith("conv_igemm") or k.startswith("conv_wgrad") or k.startswith("conv_bwd_pair") or k.startswith("wseg_wg::conv_wgrad")
     if heavy:
         if run is None: run = [r["s"], r["e"], 1]
         else: run[1] = max(run[1], r["e"]); run[2] += 1
