@@ -157,10 +157,25 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+        # RCCL prints a version banner on stdout when the communicator is created: this process's stdout carries ONE JSON line, so file
+        # descriptor 1 points at stderr while the group is set up (and the C stdio buffer is flushed before it is restored)
+        import ctypes
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev)
+            else:
+                dist.init_process_group(backend)
+            warm = torch.zeros(1, device=dev)
+            dist.all_reduce(warm)
+            torch.cuda.synchronize()
+            ctypes.CDLL(None).fflush(None)
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
 
     from wseg_amd import _lib as L
     from wseg_amd import synth
