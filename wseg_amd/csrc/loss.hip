@@ -179,9 +179,10 @@ __global__ __launch_bounds__(64) void select_scan_kernel(unsigned* __restrict__ 
     state[row * 4 + 2] = k - cum;
   }
 }
-__global__ void select_init_kernel(unsigned* __restrict__ state, unsigned* __restrict__ hist, int rows, unsigned rank_small) {
+__global__ void select_init_kernel(unsigned* __restrict__ state, unsigned* __restrict__ hist, int rows, unsigned rank_small, float* __restrict__ res) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < rows) { state[i * 4 + 0] = 0; state[i * 4 + 1] = 0; state[i * 4 + 2] = rank_small; state[i * 4 + 3] = 0; }
+  if (i < rows * 4) res[i] = 0.f;                  // (the sums the last pass accumulates into: cleared here, not by a memset launch in front of it)
   if (i < rows * 256) hist[i] = 0;
 }
 // after 4 passes state.prefix is the key of the threshold.  Accumulate per row:
@@ -1255,7 +1256,7 @@ extern "C" int wseg_select_kth(const float* vals, int rows, int n, int k, int la
   unsigned* state = (unsigned*)workspace;
   unsigned* hist = state + (size_t)rows * 4;
   const unsigned rank_small = largest ? (unsigned)(n - k + 1) : (unsigned)k;
-  hipLaunchKernelGGL(select_init_kernel, dim3((rows * 256 + 255) / 256), dim3(256), 0, ST, state, hist, rows, rank_small);
+  hipLaunchKernelGGL(select_init_kernel, dim3((rows * 256 + 255) / 256), dim3(256), 0, ST, state, hist, rows, rank_small, res);
   const int gx = std::max(1, std::min(128, (n + 4095) / 4096));  // histogram passes: enough workgroups to stream the rows (4 floats per thread and trip;
                                                                  // 32 / 64 / 128 per row measured equal, 16: +10 %, 8: +40 %)
   const int gs = std::max(1, std::min(32, (n + 8191) / 8192));   // final sums: few workgroups per row (their partials meet in same-address atomics)
@@ -1263,7 +1264,6 @@ extern "C" int wseg_select_kth(const float* vals, int rows, int n, int k, int la
     hipLaunchKernelGGL(select_hist_kernel, dim3(gx, rows), dim3(256), 0, ST, vals, n, use_abs, state, hist, shift);
     hipLaunchKernelGGL(select_scan_kernel, dim3(rows), dim3(64), 0, ST, state, hist, shift, rows);
   }
-  (void)hipMemsetAsync(res, 0, sizeof(float) * 4 * rows, ST);
   hipLaunchKernelGGL(select_sum_kernel, dim3(gs, rows), dim3(256), 0, ST, vals, n, use_abs, largest, relu_vals, state, res);
   WSEG_LAUNCH_CHECK();
   return 0;

@@ -136,6 +136,10 @@ __global__ __launch_bounds__(256) void up_stats_partial_kernel(const float* __re
   }
   if (tid == 0) { atomicMax(&kmax[pl], s_mx[0]); atomicMin(&kmin[pl], s_mn[0]); atomicAdd(&ksum[pl], s_sum[0]); }
 }
+__global__ void up_stats_init_kernel(unsigned long long* __restrict__ kmax, unsigned long long* __restrict__ kmin, float* __restrict__ ksum, long planes) {
+  const long pl = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pl < planes) { kmax[pl] = 0ull; kmin[pl] = ~0ull; ksum[pl] = 0.f; }
+}
 __global__ void up_stats_final_kernel(const unsigned long long* __restrict__ kmax, const unsigned long long* __restrict__ kmin,
                                       const float* __restrict__ ksum, float* __restrict__ stats, long planes) {
   const long pl = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -338,9 +342,7 @@ extern "C" int wseg_up_plane_stats(const float* low, float* stats, long planes, 
   unsigned long long* kmax = (unsigned long long*)workspace;
   unsigned long long* kmin = kmax + planes;
   float* ksum = (float*)(kmin + planes);
-  (void)hipMemsetAsync(kmax, 0x00, sizeof(unsigned long long) * planes, ST);
-  (void)hipMemsetAsync(kmin, 0xFF, sizeof(unsigned long long) * planes, ST);
-  (void)hipMemsetAsync(ksum, 0x00, sizeof(float) * planes, ST);
+  hipLaunchKernelGGL(up_stats_init_kernel, dim3((unsigned)((planes + 255) / 256)), dim3(256), 0, ST, kmax, kmin, ksum, planes);   // (one launch, not three memsets: these sit on the loss phase's critical chain)
   const int chunks = std::max(1, std::min(std::min(16, S / 16), (int)std::max(1L, 4096 / planes)));
   hipLaunchKernelGGL(up_stats_partial_kernel, dim3((unsigned)(planes * chunks)), dim3(256), 0, ST, low, kmax, kmin, ksum, h, w, S, chunks, label20);
   hipLaunchKernelGGL(up_stats_final_kernel, dim3((unsigned)((planes + 255) / 256)), dim3(256), 0, ST, kmax, kmin, ksum, stats, planes);
