@@ -630,7 +630,8 @@ class Engine:
                 L.resize_planar_fwd(vw["cam_low"], cam, N * 21, h, w, H, W, True)
                 L.resize_planar_fwd(rvd, cam_rv, N * 21, h, w, H, W, True)
                 outs.append((cam, cam_rv, f_proj.float() if dt == L.BF16 else f_proj, rvd))
-            vw.update(rvd=rvd.clone() if save else None, den=den)
+            # (the saved copy protects the PCM backward from a caller that edits its output in place; the fused step — lowres — only reads it)
+            vw.update(rvd=(rvd if lowres else rvd.clone()) if save else None, den=den)
         if save and self.capture_ctx:
             self.last_ctx = S
         if save:
