@@ -151,6 +151,78 @@ def step_golden(R, visualization, out_dir, name, n, size, seed, sd, py_seed, edg
     print("wrote", name, scal, "params with grad:", n_with_grad)
 
 
+def _run_body(R, visualization, n, size, seed, sd, py_seed, bf16=False):
+    """One pass of the reference's loop-body text (contrast_train.py:129-395) + backward on the reference Net; returns its namespace and the model.
+    bf16=True: the reference ITSELF with weights and activations in bfloat16 (`model.bfloat16()`, the images cast on entry, the four outputs cast back)
+    and the loss maths in float32 — what the reference shows in the storage precision of the benchmarked mode."""
+    model = R.Net()
+    model.load_state_dict(sd)
+    model.train()
+    masks = [synth.synthetic_dropout_masks(n, seed * 2 + 0), synth.synthetic_dropout_masks(n, seed * 2 + 1)]
+    if bf16:
+        model.bfloat16()
+        masks = [{k: v.bfloat16() for k, v in m.items()} for m in masks]
+    install_masks(model, masks)
+    img = synth.synthetic_images(n, size, seed)
+    lab = synth.synthetic_labels(n, seed)
+    helpers, body = body_source()
+    call = (lambda x: tuple(o.float() for o in model(x.bfloat16()))) if bf16 else model
+    ns = {"torch": torch, "F": F, "np": np, "random": random, "visualization": visualization,
+          "model": call, "pack": (None, img, lab), "args": types.SimpleNamespace(bg_threshold=0.20)}
+    exec(helpers, ns)
+    random.seed(py_seed)
+    exec(body, ns)
+    ns["loss"].backward()
+    return ns, model
+
+
+SCALAR_KEYS = ["loss", "loss_cls", "loss_er", "loss_ecr", "loss_nce", "loss_intra_nce", "loss_cross_nce", "loss_cross_nce2"]
+
+
+def step_refbf16_golden(R, visualization, out_dir, name, n, size, seed, sd, py_seed):
+    """<name>_refbf16.npz: the 8 scalars, the 13 gradient slices / norms, pseudo-labels and prototypes of the REFERENCE run in bfloat16
+    (see _run_body) on the inputs of fixture <name>.  The GPU tests hold the HIP bf16 mode's deviation from the fp32 fixture to a
+    multiple of THIS run's deviation from it (tests/test_gpu_loss.py `test_bf16_within_the_reference_bf16_envelope`)."""
+    ns, model = _run_body(R, visualization, n, size, seed, sd, py_seed, bf16=True)
+    scal = {k: float(ns[k]) for k in SCALAR_KEYS}
+    params = dict(model.named_parameters())
+    grads = {}
+    for k in GRAD_KEYS:
+        g = params[k].grad.float()
+        flat = g.reshape(-1)
+        grads["gnorm/" + k] = np.array(g.double().norm().item())
+        step = max(1, flat.numel() // 4096)
+        grads["gslice/" + k] = flat[::step][:4096].numpy().copy()
+    np.savez_compressed(
+        os.path.join(out_dir, name + "_refbf16.npz"), n=n, size=size, seed=seed, py_seed=py_seed,
+        **{"s/" + k: np.array(v) for k, v in scal.items()},
+        protos1=ns["prototypes1"].float().numpy(), protos2=ns["prototypes2"].float().numpy(),
+        pseudo1=ns["pseudo_label1"].numpy().astype(np.uint8), pseudo2=ns["pseudo_label2"].numpy().astype(np.uint8), **grads)
+    print("wrote", name + "_refbf16", scal)
+
+
+def step_margins_golden(R, visualization, out_dir, name, n, size, seed, sd, py_seed):
+    """<name>_margins.npz: the reference's OWN near-tie evidence for fixture <name> — per class and view the 33 largest values of the
+    prototype top-k input (contrast_train.py:202-203: the 32nd / 33rd gap is the selection boundary) with the 32 selected pixel indices, and per
+    contrast pixel the top-1 / top-2 gap of the pseudo-label scores (:195-197).  A differing prototype member or pseudo-label is then checked against
+    the REFERENCE's margin at that very class / pixel."""
+    ns, model = _run_body(R, visualization, n, size, seed, sd, py_seed)
+    out = {}
+    for v, (tv, ti) in (("1", ("top_values", "top_indices")), ("2", ("top_values2", "top_indices2"))):
+        rows = ns["cam_rv%s_down" % v].transpose(0, 1).reshape(21, -1)
+        t33 = torch.topk(rows, 33, dim=-1)[0]
+        assert torch.equal(t33[:, :32], ns[tv])
+        out["top33_" + v] = t33.numpy()
+        out["topidx_" + v] = ns[ti].numpy().astype(np.int32)
+        sc = ns["scores" + v]                                        # [21, n, h, w] after the transpose of :199
+        s2 = torch.topk(sc.reshape(21, -1), 2, dim=0)[0]
+        out["label_margin_" + v] = (s2[0] - s2[1]).numpy().astype(np.float32)
+    for k in SCALAR_KEYS:                                            # (the same run as the fixture: must reproduce its scalars)
+        out["s/" + k] = np.array(float(ns[k]))
+    np.savez_compressed(os.path.join(out_dir, name + "_margins.npz"), **out)
+    print("wrote", name + "_margins", {k: float(np.min(out["top33_" + k][1:, 31] - out["top33_" + k][1:, 32])) for k in "12"})
+
+
 def sgd_golden(torchutils, out_dir):
     torch.manual_seed(0)
     g = torch.Generator().manual_seed(5)
@@ -190,12 +262,16 @@ def topk_pattern_golden(out_dir):
     print("wrote bg_topk_pattern", {k: v[:4].tolist() for k, v in out.items()})
 
 
-def infer_golden(R, out_dir, sd, name="infer_1img", H=40, W=56, classes=(3, 11), seed0=40, store_stride=1):
+def infer_golden(R, out_dir, sd, name="infer_1img", H=40, W=56, classes=(3, 11), seed0=40, store_stride=1, extras=None):
     """contrast_infer.py:49-99 on one synthetic image: the 8 MSF inputs (4 scales x flip, sizes round(H*s) x round(W*s) as
     voc12/data.py:100-121 makes them), the reference Net, and the reference's own post-process text (:75-80, :97-98)."""
+    # extras = "margins": write <name>_margins.npz (the reference's per-pixel top-1 / top-2 margin of [alpha, present classes], float16) instead of
+    # the fixture; extras = "refbf16": <name>_refbf16.npz, the arg-max map of the reference run in bfloat16 (model.bfloat16(), post-process in f32)
     model = R.Net()
     model.load_state_dict(sd)
     model.eval()
+    if extras == "refbf16":
+        model.bfloat16()
     lab = torch.zeros(20)
     lab[list(classes)] = 1
     imgs = []
@@ -206,8 +282,8 @@ def infer_golden(R, out_dir, sd, name="infer_1img", H=40, W=56, classes=(3, 11),
     cam_list = []
     for i, img in enumerate(imgs):
         with torch.no_grad():                                       # contrast_infer.py:58-66
-            _, cam, _, _ = model(img)
-            cam = F.interpolate(cam[:, 1:, :, :], (H, W), mode="bilinear", align_corners=False)[0]
+            _, cam, _, _ = model(img.bfloat16() if extras == "refbf16" else img)
+            cam = F.interpolate(cam.float()[:, 1:, :, :], (H, W), mode="bilinear", align_corners=False)[0]
             cam = cam.numpy() * lab.clone().view(20, 1, 1).numpy()
             if i % 2 == 1:
                 cam = np.flip(cam, axis=-1)
@@ -219,6 +295,17 @@ def infer_golden(R, out_dir, sd, name="infer_1img", H=40, W=56, classes=(3, 11),
     exec(post, ns)
     exec(pred_src, ns)
     norm_cam = ns["norm_cam"].astype(np.float32)
+    if extras == "refbf16":
+        np.savez_compressed(os.path.join(out_dir, name + "_refbf16.npz"), H=H, W=W, pred=ns["pred"].astype(np.uint8))
+        print("wrote", name + "_refbf16", np.bincount(ns["pred"].reshape(-1)))
+        return
+    if extras == "margins":
+        stack = np.concatenate([np.full((1, H, W), 0.26, np.float32), norm_cam[sorted(classes)]], axis=0)
+        top2 = np.sort(stack, axis=0)[-2:]
+        np.savez_compressed(os.path.join(out_dir, name + "_margins.npz"), H=H, W=W, classes=np.array(sorted(classes)),
+                            margin=(top2[1] - top2[0]).astype(np.float16), pred=ns["pred"].astype(np.uint8))
+        print("wrote", name + "_margins", float((top2[1] - top2[0]).min()))
+        return
     extra = {}
     if name == "infer_1img":
         extra["norm_cam"] = norm_cam                                 # (round-1 layout: all 20 planes)
@@ -326,7 +413,7 @@ def eval_golden(out_dir):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
-    ap.add_argument("--only", default="", help="comma list of: fwd,step,step448,step_edge,sgd,topk,infer,infer_ms,infer_full,multistep,eval")
+    ap.add_argument("--only", default="", help="comma list of: fwd,step,step448,step_edge,sgd,topk,infer,infer_ms,infer_full,multistep,eval,refbf16,margins")
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     torch.manual_seed(0)
@@ -360,6 +447,17 @@ def main():
         infer_golden(R, a.out, sd, "infer_188x250", 188, 250, (5,), seed0=60)
     if "infer_full" in todo:
         infer_golden(R, a.out, sd, "infer_375x500", 375, 500, (1, 16), seed0=70, store_stride=3)
+    if "refbf16" in todo:                            # the reference itself in bfloat16: the envelope of the benchmarked mode
+        step_refbf16_golden(R, visualization, a.out, "step_S160_N2", 2, 160, 21, sd, py_seed=7)
+        step_refbf16_golden(R, visualization, a.out, "step_S448_N2", 2, 448, 23, sd, py_seed=6)
+        step_refbf16_golden(R, visualization, a.out, "step_S448_N2_b", 2, 448, 24, sd, py_seed=6)
+        infer_golden(R, a.out, sd, "infer_188x250", 188, 250, (5,), seed0=60, extras="refbf16")
+    if "margins" in todo:                            # the reference's own near-tie margins (prototype top-32 boundary, pseudo-labels, arg-max maps)
+        step_margins_golden(R, visualization, a.out, "step_S448_N2", 2, 448, 23, sd, py_seed=6)
+        step_margins_golden(R, visualization, a.out, "step_S448_N2_b", 2, 448, 24, sd, py_seed=6)
+        infer_golden(R, a.out, sd, "infer_125x94", 125, 94, (0, 7, 14), seed0=50, extras="margins")
+        infer_golden(R, a.out, sd, "infer_188x250", 188, 250, (5,), seed0=60, extras="margins")
+        infer_golden(R, a.out, sd, "infer_375x500", 375, 500, (1, 16), seed0=70, extras="margins")
     if "multistep" in todo:
         multistep_golden(R, visualization, torchutils, a.out, "step_S128_N3_x3", 3, 128, 51, sd, py_seed=9, steps=3,
                          lr=float(os.environ.get("WSEG_GOLDEN_LR", "3e-6")), max_step=10)

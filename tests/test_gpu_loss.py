@@ -336,6 +336,32 @@ def test_bf16_three_steps_against_reference_fixture(golden_dir, proc_sd):
             assert abs(scal[s_][k] - ref) <= BF16_SCALAR_BAR[k] * abs(ref), (s_, k, scal[s_][k], ref)
 
 
+def test_lookahead_prefix_dropped_when_frozen_state_changes(proc_sd):
+    """The lookahead prefix (conv1a + frozen b2* with folded BNs) also depends on the frozen weights and BN buffers: a BN-buffer edit
+    (as load_state_dict / a checkpoint resume makes) between `step(i, next_img1=x)` and `step(x)` must drop it (Engine.frozen_key)."""
+    from wseg_amd import synth
+    n, size, seed = 2, 96, 43
+    imgs = [synth.synthetic_images(n, size, seed + j).cuda() for j in range(2)]
+    labs = [synth.synthetic_labels(n, seed + j).cuda() for j in range(2)]
+    outs = []
+    for look in (False, True):
+        model, opt, tr = _trainer(proc_sd, "fp32", "hip", n, seed, 4, lr=3e-6)
+        model.set_dropout_masks(None)
+        tr.rng_parity = False
+        os.environ["WSEG_INTRA_KEY_SEED"] = "9"
+        torch.manual_seed(17)
+        try:
+            tr.step(imgs[0], labs[0], next_img1=imgs[1] if look else None)
+            with torch.no_grad():
+                model.b2.bn_branch2a.running_mean.add_(0.25)                      # the frozen prefix now computes something else
+            got = tr.step(imgs[1], labs[1])
+            outs.append({k: float(v) for k, v in got.items()})
+        finally:
+            del os.environ["WSEG_INTRA_KEY_SEED"]
+    for k in SCALARS:
+        assert abs(outs[0][k] - outs[1][k]) <= 5e-5 * max(1.0, abs(outs[0][k])), (k, outs[0][k], outs[1][k])
+
+
 @pytest.mark.parametrize("P", [4096, 1000, 300007])
 def test_fused_nce_matches_the_unfused_formulation(P):
     """csrc/loss.hip nce_records + nce_fused (the product path: both views in one launch, nothing but records / dF written)

@@ -100,20 +100,20 @@ class Engine:
         return (type(None), ())             # pickling a whole Net: the engine is derived state
 
     def ensure_flat(self, device):
-        """(Re)build the flat weight / gradient buffers when the parameters moved.  Serialised: eight inference threads may
-        enter a fresh module at once (contrast_infer.py:69-73)."""
+        """(Re)build the flat weight / gradient buffers when the parameters moved, and return the engine whose buffers serve this
+        module on `device`: itself, or the original's for an aliasing replica.  Serialised: eight inference threads may enter a fresh
+        module at once (contrast_infer.py:69-73); callers use the RETURNED engine — `self.delegate` is written exactly once per call,
+        under the lock, and never passes through None while another thread may be reading it."""
         with self.lock:
-            self._ensure_flat(device)
+            return self._ensure_flat(device)
 
     def active(self, device):
         """The engine whose buffers serve this module on `device`: itself, or the original's for an aliasing replica."""
-        self.ensure_flat(device)
-        return self.delegate if self.delegate is not None else self
+        return self.ensure_flat(device)
 
     def _ensure_flat(self, device):
         names = self.trainable_order()
         first = self.conv_param(names[0])
-        self.delegate = None
         par = self.parent
         if par is not None:
             # a replica on the original's device holds ALIASES of the original's parameters (nn.parallel.replicate hands device 0
@@ -123,10 +123,11 @@ class Engine:
                 if (par.flat_w is not None and first.device == par.flat_w.device == device
                         and first.data_ptr() == par.flat_w.data_ptr()):
                     self.delegate = par
-                    return
+                    return par
         if (self.flat_w is not None and self.flat_w.device == first.device
                 and first.data_ptr() == self.flat_w.data_ptr() and first.device == device):
-            return
+            self.delegate = None
+            return self
         total = sum(self.conv_param(n).numel() for n in names)
         flat_w = torch.empty(total, device=device, dtype=torch.float32)
         flat_g = torch.zeros(total, device=device, dtype=torch.float32)
@@ -147,6 +148,8 @@ class Engine:
         self.flat_w, self.flat_g = flat_w, flat_g
         self.packs = None
         self.flat_wb_version = None                          # the bf16 mirror (if any) is stale
+        self.delegate = None
+        return self
 
     def _mirror_fresh(self, names):
         """False when a parameter was modified through torch (load_state_dict, manual edits) since the mirror was written."""
@@ -201,6 +204,17 @@ class Engine:
         L.pack_x3(w32.contiguous(), out)
         return out
 
+    def frozen_key(self, device, dt):
+        """Identity of everything the frozen prefix (conv1a, b2*, every folded BatchNorm) is computed from: precision, device, the versions of
+        all buffers / BN parameters / frozen conv weights.  The frozen packs are rebuilt when it changes, and a lookahead prefix computed under
+        another key is dropped (Trainer.step)."""
+        net = self.net
+        frozen_names = [c[0] for b in arch.BLOCKS if b[0] in arch.FROZEN_BLOCKS for c in arch.block_convs(b)]
+        return (dt, str(device)) + tuple(b._version for b in net.buffers()) + \
+            tuple(p._version for n_, p in net.named_parameters() if ".bn" in n_ or n_.startswith("bn7")) + \
+            tuple((self.conv_param(n_)._version, self.conv_param(n_).data_ptr()) for n_ in frozen_names) + \
+            (net.conv1a.weight._version, net.conv1a.weight.data_ptr())
+
     def ensure_packs(self, device, dt, defer_wt=False, late_stream=None):
         with self.lock:
             return self._ensure_packs(device, dt, defer_wt, late_stream)
@@ -214,10 +228,7 @@ class Engine:
         otherwise sit in front of every step) are made on that stream; the forward pass waits for them where it first uses one (`_join_late_packs`)."""
         net = self.net
         tdt = L.TORCH_DTYPE[dt]
-        frozen_names = [c[0] for b in arch.BLOCKS if b[0] in arch.FROZEN_BLOCKS for c in arch.block_convs(b)]
-        fkey = (dt, str(device)) + tuple(b._version for b in net.buffers()) + \
-            tuple(p._version for n_, p in net.named_parameters() if ".bn" in n_ or n_.startswith("bn7")) + \
-            tuple(self.conv_param(n_)._version for n_ in frozen_names) + (net.conv1a.weight._version, net.conv1a.weight.data_ptr())
+        fkey = self.frozen_key(device, dt)
         if getattr(self, "_frozen_packs", None) is None or self._frozen_key != fkey:
             F_ = {"w": {}, "bn": {}}
             for b in arch.BLOCKS:
@@ -405,9 +416,9 @@ class Engine:
         if not x.is_cuda:
             raise RuntimeError("wseg_amd.Net runs only on an MI355X (HIP) device; there is no CPU fallback")
         x = x.contiguous().float()
-        self.ensure_flat(x.device)
-        if self.delegate is not None:                         # replica whose parameters alias the original's flat buffer
-            return self.delegate.forward(x, lowres)
+        act = self.ensure_flat(x.device)
+        if act is not self:                                   # replica whose parameters alias the original's flat buffer
+            return act.forward(x, lowres)
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.net.parameters())
         if need_grad:
             anchor = self.flat_w.new_zeros((), requires_grad=True)

@@ -12,6 +12,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib as L
+from .engine import DT_OF
 
 
 def dist_state():
@@ -67,7 +68,10 @@ class Trainer:
         from . import loss_hip
         img1 = img1.contiguous().float()
         pre, self._lookahead = getattr(self, "_lookahead", None), None
-        if pre is not None and pre["img1"].data_ptr() == img1.data_ptr() and pre["img1"].shape == img1.shape and pre["version"] == img1._version:
+        # the prefix is reused only for the SAME image tensor AND the same frozen weights / BN buffers / precision it was computed from
+        # (a load_state_dict or a BN-buffer edit between the two calls changes Engine.frozen_key: the stale activations are dropped)
+        if (pre is not None and pre["img1"].data_ptr() == img1.data_ptr() and pre["img1"].shape == img1.shape and pre["version"] == img1._version
+                and pre.get("fkey") == self.model._engine.frozen_key(img1.device, DT_OF[self.model.precision])):
             img2, prefix = pre["img2"], pre["prefix"]
         else:
             img2, prefix = second_view(img1), None
@@ -79,6 +83,8 @@ class Trainer:
         self.optimizer.zero_grad(flat=False)                # (the fused step clears the flat gradient buffer itself, off the critical path)
         losses = loss_hip.step(self.model, img1, img2, label20, self.bg_threshold, self.rng, self.rng_parity,
                                self.bg_topk_idx, zero_grads=True, prefix=prefix, lookahead=la)
+        if la is not None:
+            la["fkey"] = self.model._engine.frozen_key(img1.device, DT_OF[self.model.precision])
         self._lookahead = la
         return self.finish_step(losses)
 
