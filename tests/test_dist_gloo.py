@@ -1,4 +1,4 @@
-"""Multi-rank protocol on CPU ranks (gloo, world_size 2) — SURVEY.md §8e.
+"""Multi-rank protocol on CPU ranks (gloo, world_size 2 and 4) — SURVEY.md §8e.
 
 What shards and what is exchanged:
   (1) gradients: every rank's flat buffer is all-reduced (SUM) and the fused SGD scales by 1/world;
@@ -85,7 +85,9 @@ def _worker(rank, world, port, tmp):
         dist.destroy_process_group()
 
 
-def test_world2_prototype_and_gradient_exchange(tmp_path):
+@pytest.mark.parametrize("world", [2, 4])
+def test_prototype_and_gradient_exchange(tmp_path, world):
+    """world 2 and world 4 (one image per rank: the class that is constant on the last two ranks only must lose the merge by value)"""
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))

@@ -200,6 +200,33 @@ def test_prototype_exchange_two_ranks_on_one_gpu():
     np.testing.assert_allclose(p3.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-6)
 
 
+def test_prototype_merge_eight_ranks():
+    """proto_merge at BASELINE config 3's world size (8 x 32 candidates per class, ranked by counting): the eight ranks' candidate lists of
+    a 16-image batch == one pass over the whole batch; with values tied ACROSS ranks (the lowest global pixel must win) and a class that is
+    constant on every rank (the tie table of rank 0)."""
+    from tests.test_dist_gloo import local_candidates, merge
+    from wseg_amd import _lib as L
+    dev = "cuda"
+    g = torch.Generator().manual_seed(8)
+    n, npix, K, world = 16, 256, 32, 8
+    ncam = (torch.rand(n, 21, npix, generator=g) * 64).round() / 64           # many exact ties, also across ranks
+    ncam[:, 0] = 0.2; ncam[:, 7] = -1.0; ncam[4:, 9] = -1.0
+    feat = torch.randn(n * npix, 128, generator=g)
+    tie = torch.arange(K, dtype=torch.int32)
+    per = n // world
+    cvs, cfs, ccs = [], [], []
+    for r in range(world):
+        cv = torch.empty(21, K, device=dev); cf = torch.empty(21, K, 128, device=dev); cc = torch.empty(21, device=dev, dtype=torch.int32)
+        L.proto_candidates(ncam[r * per:(r + 1) * per].contiguous().to(dev), feat[r * per * npix:(r + 1) * per * npix].contiguous().to(dev),
+                           tie.to(dev), cv, cf, cc, per, npix, K)
+        cvs.append(cv); cfs.append(cf); ccs.append(cc)
+    p8 = torch.empty(21, 128, device=dev)
+    L.proto_merge(torch.stack(cvs), torch.stack(cfs), torch.stack(ccs), p8, world, K)
+    rv, rf, rc = local_candidates(ncam, feat, K, tie.long())
+    ref = merge(rv[None], rf[None], rc[None])
+    np.testing.assert_allclose(p8.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-6)
+
+
 @pytest.mark.parametrize("img_hw,crop,prec,dev_aug", [((96, 128), 128, "bf16", False), ((448, 448), 448, "fp32", False), ((375, 500), 448, "bf16x3", True)])
 def test_cli_plumbing_train_then_infer(tmp_path, monkeypatch, img_hw, crop, prec, dev_aug):
     """BASELINE.json config 1 on the GPU path: 4 synthetic VOC-format JPEGs, batch_size 2, 1 epoch -> contrast.pth ->

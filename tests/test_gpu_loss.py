@@ -415,13 +415,14 @@ def test_fused_nce_matches_the_unfused_formulation(P):
     assert torch.equal(w21, w1)
 
 
-@pytest.mark.parametrize("ranks", [1, 2])
+@pytest.mark.parametrize("ranks", [1, 2, 8])
 def test_intra_weights_global_matches_sorted_kernel(ranks):
-    """Hard-pixel sampling over the gathered batch (radix-select thresholds on the all-gathered records) against the
-    single-rank sort-based kernel run on the concatenated global arrays: identical weights for every rank's slice."""
+    """Hard-pixel sampling over the gathered batch (radix-select thresholds on the all-gathered records, one workgroup per class)
+    against the single-rank sort-based kernel run on the concatenated global arrays: identical weights for every rank's slice.
+    ranks = 8: the world size of BASELINE config 3 (P = 1024 per rank here: the sort-based reference kernel holds at most 8192 pixels)."""
     from wseg_amd import _lib as L
     dev = "cuda"
-    P = 1536
+    P = 1536 if ranks < 8 else 1024
     g = torch.Generator().manual_seed(11 + ranks)
     PG = P * ranks
     y = torch.randint(0, 21, (PG,), generator=g, dtype=torch.int32)

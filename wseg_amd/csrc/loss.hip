@@ -516,21 +516,25 @@ __global__ __launch_bounds__(256) void proto_candidates_kernel(const float* __re
 // merge world*K candidates per class -> top K -> weighted mean -> L2 normalise (F.normalize eps 1e-12)
 __global__ __launch_bounds__(128) void proto_merge_kernel(const float* __restrict__ cand_val, const float* __restrict__ cand_feat, const int* __restrict__ cand_const,
                                                           float* __restrict__ protos, int world, int K, long rs_val, long rs_feat, long rs_const) {
-  __shared__ float vals[512]; __shared__ int order[64]; __shared__ float red[2];
+  __shared__ float vals[512]; __shared__ int order[64]; __shared__ float red[2]; __shared__ int cst_s;
   const int c = blockIdx.x, tid = threadIdx.x;
   const int M = world * K;                                  // rank w's [21][K] values / [21][K][128] features / [21] flags at w * rs_*
   for (int i = tid; i < M; i += 128) { const int w = i / K, k = i - w * K; vals[i] = cand_val[(size_t)w * rs_val + c * K + k]; }
-  __syncthreads();
   if (tid == 0) {
     bool cst = true;
     for (int w = 0; w < world; ++w) cst = cst && cand_const[(size_t)w * rs_const + c];
-    if (cst) { for (int k = 0; k < K; ++k) order[k] = k; }  // fully tied: rank 0's set (global pixels first)
-    else {
-      for (int k = 0; k < K; ++k) {
-        float bv = -INFINITY; int bi = 0;
-        for (int i = 0; i < M; ++i) if (vals[i] > bv) { bv = vals[i]; bi = i; }
-        order[k] = bi; vals[bi] = -INFINITY;
-      }
+    cst_s = cst ? 1 : 0;
+  }
+  __syncthreads();
+  if (cst_s) { if (tid < K) order[tid] = tid; }             // fully tied: rank 0's set (global pixels first)
+  else {
+    // rank by counting (round 2 selected serially on one thread: K x M compares, 40 us at world 8): candidate i is the
+    // (#{j : v_j > v_i or (v_j == v_i and j < i)})-th largest — the order of K rounds of "first maximum"
+    for (int i = tid; i < M; i += 128) {
+      const float v = vals[i];
+      int r = 0;
+      for (int j = 0; j < M; ++j) { const float u = vals[j]; r += (u > v || (u == v && j < i)) ? 1 : 0; }
+      if (r < K) order[r] = i;
     }
   }
   __syncthreads();
@@ -675,76 +679,93 @@ __global__ void intra_pack_kernel(const int* __restrict__ y, const float* __rest
 }
 // intra_weights_global: `rec` = gathered records, rank r's [3][P] block at rec + r*rank_stride (global pixel g = r*P + p).  Per class c with
 // len >= 2 pixels the reference keeps (a) a random half and (b) the pixels whose similarity rank lies in
-// [int(0.6 len) - len/2, int(0.6 len)); both are order statistics of unique 56-bit keys (value << 24 | g), found
-// by a 7-pass radix select for all 21 x 3 thresholds at once (one workgroup, histograms in LDS) — no global sort.
-// Writes this rank's weights: w[p] = scale * (#selections of p) / (2 * (len/2) * classes present).
+// [int(0.6 len) - len/2, int(0.6 len)); both are order statistics of unique 56-bit keys (value << 24 | g), found by a 7-pass radix
+// select — no global sort.  ONE WORKGROUP PER CLASS (grid 21; round 2 ran all 63 selections in a single workgroup, which at world 8 —
+// 32 768 records per view — sat serially between the all-gather and the fused NCE launch): workgroup c counts its members (and which classes
+// occur at all), runs the three selections of its class over the gathered records (per-wave private histograms: the first digit of a
+// similarity or a uniform key is the same for most of a class, so a shared histogram serialises on two or three buckets), and writes the
+// weights of ITS class's pixels of this rank: w[p] = scale * (#selections of p) / (2 * (len/2) * classes present).
 __global__ __launch_bounds__(1024) void intra_weights_global_kernel(const float* __restrict__ rec, float* __restrict__ w, int P, int ranks,
                                                                     int own_rank, float scale, long rank_stride) {
-  __shared__ unsigned hist[63][256];
-  __shared__ unsigned long long prefix[63];
-  __shared__ unsigned remaining[63];
-  __shared__ int cnt[21], nclass;
+  __shared__ unsigned hist[16][3][256];                       // [wave][selection][bucket]
+  __shared__ unsigned long long prefix[3];
+  __shared__ unsigned remaining[3];
+  __shared__ int present[21], cnt_s, nclass_s;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int c = blockIdx.x;
   const int PG = P * ranks;
   auto label = [&](int g) { const int r = g / P; return __float_as_int(rec[(size_t)r * rank_stride + (g - r * P)]); };
   auto key = [&](int g, int which) {              // which: 1 = similarity, 2 = random key
     const int r = g / P;
     return ((unsigned long long)f2key(rec[(size_t)r * rank_stride + (size_t)which * P + (g - r * P)]) << 24) | (unsigned long long)g;
   };
-  if (tid < 21) cnt[tid] = 0;
+  if (tid < 21) present[tid] = 0;
+  if (tid == 0) cnt_s = 0;
   __syncthreads();
-  for (int g = tid; g < PG; g += 1024) atomicAdd(&cnt[label(g)], 1);
+  int mine = 0;
+  for (int g = tid; g < PG; g += 1024) {
+    const int l = label(g);
+    present[l] = 1;                                          // (plain store: every writer writes the same value)
+    mine += l == c ? 1 : 0;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+  if (lane == 0 && mine) atomicAdd(&cnt_s, mine);
   __syncthreads();
-  if (tid == 0) { int C = 0; for (int c = 0; c < 21; ++c) if (cnt[c] > 0) ++C; nclass = C; }
-  if (tid < 63) {
-    const int c = tid / 3, j = tid - c * 3, len = cnt[c], half = len / 2, kk = (int)((double)len * 0.6);
+  if (tid == 0) { int C = 0; for (int k = 0; k < 21; ++k) C += present[k]; nclass_s = C; }
+  const int len = cnt_s, half = len / 2, kk = (int)((double)len * 0.6);
+  const int g0 = own_rank * P;
+  if (len < 2) {                                             // (uniform) absent or single-pixel class: counted in C, no term (contrast_train.py:312-313)
+    for (int p = tid; p < P; p += 1024) if (label(g0 + p) == c) w[p] = 0.f;
+    return;
+  }
+  if (tid < 3) {
     prefix[tid] = 0ull;
-    remaining[tid] = (unsigned)(j == 0 ? kk - half : (j == 1 ? kk : half));     // 0-based target rank within the class
+    remaining[tid] = (unsigned)(tid == 0 ? kk - half : (tid == 1 ? kk : half));     // 0-based target rank within the class
   }
   for (int shift = 48; shift >= 0; shift -= 8) {
-    for (int i = tid; i < 63 * 256; i += 1024) (&hist[0][0])[i] = 0u;
+    for (int i = tid; i < 16 * 3 * 256; i += 1024) (&hist[0][0][0])[i] = 0u;
     __syncthreads();
+    const unsigned long long pf0 = prefix[0], pf1 = prefix[1], pf2 = prefix[2];
     for (int g = tid; g < PG; g += 1024) {
-      const int c = label(g);
-      if (cnt[c] < 2) continue;
+      if (label(g) != c) continue;
       const unsigned long long ks = key(g, 1), kr = key(g, 2);
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const unsigned long long k = j == 2 ? kr : ks;
-        const int s = c * 3 + j;
-        if (shift == 48 || (k >> (shift + 8)) == (prefix[s] >> (shift + 8))) atomicAdd(&hist[s][(unsigned)(k >> shift) & 255u], 1u);
-      }
+      const unsigned bs = (unsigned)(ks >> shift) & 255u, br = (unsigned)(kr >> shift) & 255u;
+      if (shift == 48 || (ks >> (shift + 8)) == (pf0 >> (shift + 8))) atomicAdd(&hist[wv][0][bs], 1u);
+      if (shift == 48 || (ks >> (shift + 8)) == (pf1 >> (shift + 8))) atomicAdd(&hist[wv][1][bs], 1u);
+      if (shift == 48 || (kr >> (shift + 8)) == (pf2 >> (shift + 8))) atomicAdd(&hist[wv][2][br], 1u);
     }
     __syncthreads();
-    for (int s = wv; s < 63; s += 16) {            // one wave per selection: lane l owns buckets 4l..4l+3
-      const unsigned rem = remaining[s];
-      const unsigned c0 = hist[s][lane * 4], c1 = hist[s][lane * 4 + 1], c2 = hist[s][lane * 4 + 2], c3 = hist[s][lane * 4 + 3];
-      const unsigned sum = c0 + c1 + c2 + c3;
+    if (wv < 3) {                                  // one wave per selection: lane l owns buckets 4l..4l+3 (summed over the 16 private copies)
+      const int s_ = wv;
+      unsigned cs[4] = {0u, 0u, 0u, 0u};
+      for (int k = 0; k < 16; ++k) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cs[j] += hist[k][s_][lane * 4 + j];
+      }
+      const unsigned rem = remaining[s_];
+      const unsigned sum = cs[0] + cs[1] + cs[2] + cs[3];
       unsigned inc = sum;
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
       unsigned cum = inc - sum;
       if (cum <= rem && rem < inc) {               // exactly one lane when the class holds more than `rem` pixels
-        const unsigned cs[4] = {c0, c1, c2, c3};
         int b = -1;
 #pragma unroll
         for (int j = 0; j < 4; ++j) if (b < 0) { if (rem < cum + cs[j]) b = lane * 4 + j; else cum += cs[j]; }
-        prefix[s] |= (unsigned long long)b << shift;
-        remaining[s] = rem - cum;
+        prefix[s_] |= (unsigned long long)b << shift;
+        remaining[s_] = rem - cum;
       }
     }
     __syncthreads();
   }
-  const int g0 = own_rank * P;
+  const float unit = scale / (2.f * (float)half * (float)nclass_s);
   for (int p = tid; p < P; p += 1024) {
-    const int g = g0 + p, c = label(g), len = cnt[c];
-    float wp = 0.f;
-    if (len >= 2) {
-      const unsigned long long ks = key(g, 1), kr = key(g, 2);
-      const int n_sel = (ks >= prefix[c * 3 + 0] && ks < prefix[c * 3 + 1] ? 1 : 0) + (kr < prefix[c * 3 + 2] ? 1 : 0);
-      wp = scale * (float)n_sel / (2.f * (float)(len / 2) * (float)nclass);
-    }
-    w[p] = wp;
+    const int g = g0 + p;
+    if (label(g) != c) continue;
+    const unsigned long long ks = key(g, 1), kr = key(g, 2);
+    const int n_sel = (ks >= prefix[0] && ks < prefix[1] ? 1 : 0) + (kr < prefix[2] ? 1 : 0);
+    w[p] = unit * (float)n_sel;
   }
 }
 
@@ -1379,7 +1400,7 @@ extern "C" int wseg_intra_pack(const int* y, const float* S_own, const float* rk
 extern "C" int wseg_intra_weights_global(const float* rec, float* w, int P, int ranks, int own_rank, float scale, long rank_stride, void* stream) {
   WSEG_CHECK(rec && w && P > 0 && ranks > 0 && own_rank >= 0 && own_rank < ranks && (long)P * ranks < (1L << 24) && rank_stride >= 3L * P,
              "intra_weights_global: bad arguments (P=%d ranks=%d own=%d)", P, ranks, own_rank);
-  hipLaunchKernelGGL(intra_weights_global_kernel, dim3(1), dim3(1024), 0, ST, rec, w, P, ranks, own_rank, scale, rank_stride);
+  hipLaunchKernelGGL(intra_weights_global_kernel, dim3(21), dim3(1024), 0, ST, rec, w, P, ranks, own_rank, scale, rank_stride);   // one workgroup per class
   WSEG_LAUNCH_CHECK();
   return 0;
 }
