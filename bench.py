@@ -64,6 +64,97 @@ def cpu_baseline(sizes=(2, 16), size=448):
                       + f"; value = the N={n} run; nproc={os.cpu_count()}"}
 
 
+def kernel_source_sha1():
+    """sha1 over the conv / weight-gradient kernel sources: scripts/summarize_pmc.py stores it in the PMC traffic summary, and the bench line
+    says whether the kernels of THIS build are the ones the traffic was measured on (a stale summary is then visible, not silent)."""
+    import hashlib
+    h = hashlib.sha1()
+    for f in ("conv_igemm.hip", "conv_wgrad_kernels.h", "conv_wgrad.hip", "common.h"):
+        with open(os.path.join(ROOT, "wseg_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+SIM_BYTES_RECORDS, SIM_BYTES_FUSED = 532, 1036      # SURVEY.md §8d: algorithmic bytes per pixel (features read once; records / dF written)
+HBM_PEAK_GBS = 8000.0
+
+
+def similarity_section(dev):
+    """The north star's second target — the pixel-to-prototype similarity (contrast_train.py:245-334) against the HBM roof — measured in
+    process: `nce_records` (the similarity contraction -> hard-pixel records) and `nce_fused` (similarities + 3 InfoNCE terms + gradient),
+    both views per launch, at the step's real P = 4096 pixels per view (launch-bound: SURVEY.md §8d says no bandwidth fraction is reachable there)
+    and at P = 2^20 per view (the kernels' streaming rate); HIP events, SURVEY.md §8d's algorithmic bytes / time."""
+    from wseg_amd import _lib as L
+
+    def run(P, iters):
+        g = torch.Generator(device=dev).manual_seed(P)
+        V = []
+        for _ in range(2):
+            F = torch.randn(P, 128, device=dev, generator=g)
+            V.append(dict(F=F, p=torch.nn.functional.normalize(torch.randn(21, 128, device=dev, generator=g), dim=1),
+                          y=torch.randint(0, 21, (P,), device=dev, dtype=torch.int32, generator=g), w=torch.rand(P, device=dev, generator=g) / P,
+                          dF=torch.empty_like(F), rkey=torch.rand(P, device=dev, generator=g), rec=torch.empty(3, P, device=dev)))
+        sums = torch.zeros(3, device=dev)
+        rv = [dict(F=v["F"], p_own=v["p"], y_own=v["y"], rkey=v["rkey"], rec=v["rec"]) for v in V]
+        fv = [dict(F=v["F"], p_own=v["p"], p_oth=o["p"], y_own=v["y"], y_oth=o["y"], w_intra=v["w"], dF=v["dF"]) for v, o in ((V[0], V[1]), (V[1], V[0]))]
+
+        def t(fn):
+            fn(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                fn()
+            e1.record(); torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / iters * 1e3       # us
+        out = {}
+        for name, fn, bpp, protos in (("records", lambda: L.nce_records(rv, P, split_bf16=True), SIM_BYTES_RECORDS, 1),
+                                      ("records_f32", lambda: L.nce_records(rv, P), SIM_BYTES_RECORDS, 1),
+                                      ("fused", lambda: L.nce_fused(fv, P, 0.1 / (2 * P), 0.05, sums), SIM_BYTES_FUSED, 2)):
+            us = t(fn)
+            nbytes = 2 * (P * bpp + protos * 21 * 128 * 4)
+            out[name] = {"us": round(us, 2), "GBps": round(nbytes / us / 1e3, 1), "frac_of_8TBps": round(nbytes / us / 1e3 / HBM_PEAK_GBS, 4)}
+        return out
+    return {"bound": "hbm", "peak_GBps": HBM_PEAK_GBS, "bytes_per_pixel": {"records": SIM_BYTES_RECORDS, "fused": SIM_BYTES_FUSED},
+            "note": "both views per launch; `records` = the similarity contraction of the bf16 / bf16x3 modes (split-bf16 products), `records_f32` = exact-f32 MFMA (fp32 mode), "
+                    "`fused` = similarities + InfoNCE + gradient (exact f32 in every mode)",
+            "P4096_real_shape": run(4096, 50), "P1048576_sweep": run(1 << 20, 3)}
+
+
+def infer_section(dev, n_img=8):
+    """BASELINE config 5's geometry (contrast_infer.py:49-99: one 375 x 500 image, scales 0.5 / 1 / 1.5 / 2 x flip = 8 forwards, post-process) on
+    inputs resident in HBM, bf16 mode: images/s, ms/image and the fraction of the dense bf16 MFMA peak over the algorithmic FLOPs of the 8
+    forwards (wseg_amd.arch.forward_macs: SURVEY.md §8d's counting)."""
+    import torch.nn.functional as F
+    from wseg_amd import arch, synth
+    from wseg_amd.infer import infer_image
+    from wseg_amd.resnet38_contrast import Net
+    H, W = 375, 500
+    model = Net(precision="bf16")
+    model.load_state_dict(synth.procedural_state_dict(0, device=dev))
+    model.eval(); model.cuda(dev)
+    g = torch.Generator().manual_seed(0)
+    base = torch.randn(1, 3, H, W, generator=g).to(dev)
+    label = torch.zeros(20); label[[3, 11]] = 1
+    lst, flops = [], 0.0
+    for s_ in (0.5, 1.0, 1.5, 2.0):
+        hs, ws = int(round(H * s_)), int(round(W * s_))
+        im = F.interpolate(base, size=(hs, ws), mode="bicubic", align_corners=False)
+        lst += [im, im.flip(-1)]
+        flops += 2 * 2.0 * arch.forward_macs(hs, ws)
+    for _ in range(2):
+        infer_image(model, lst, label, (H, W))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n_img):
+        infer_image(model, lst, label, (H, W))
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n_img
+    return {"workload": "contrast_infer multi-scale CAM, one synthetic 375x500 image = 8 forwards (scales 0.5/1/1.5/2 x flip) + post-process, inputs resident, bf16",
+            "images_per_sec": round(1.0 / dt, 2), "ms_per_image": round(dt * 1e3, 2), "forwards_per_image": 8, "images_timed": n_img,
+            "algorithmic_tflop_per_image": round(flops / 1e12, 3), "achieved_tflops": round(flops / dt / 1e12, 1),
+            "frac_of_bf16_peak": round(flops / dt / 1e12 / PEAK_BF16_TFLOPS, 4), "val_set_1449_images_sec": round(1449 * dt, 1)}
+
+
 def _spawn_ranks(a):
     """--gpus N without a launcher: start `torch.distributed.run` as a child process (this process has made no GPU call)."""
     with socket.socket() as s_:
@@ -119,6 +210,7 @@ def main():
     ap.add_argument("--size", type=int, default=448)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16x3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the `similarity` (HBM roof of the pixel-to-prototype kernels) and `infer_mode` (config 5 geometry) sections")
     ap.add_argument("--cpu-baseline-n", default="2,16", help="batch sizes of the CPU-oracle leg (BASELINE.md §3: N=2 and N=16)")
     ap.add_argument("--parity-steps", type=int, default=2,
                     help="timed steps of the parity (f32-exact) mode reported as `parity_mode` beside the bf16 line (0: skip)")
@@ -230,16 +322,19 @@ def main():
         n_launch = max(1, len(per_idx)) * a.steps
         peak = PEAKS[a.precision]
         achieved = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
-        traffic, traffic_src = None, None
+        traffic, traffic_src, traffic_fresh = None, None, None
         try:                                                   # HBM bytes per launch from the committed PMC passes
             import glob                                        # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 on gfx950)
             f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]
-            traffic = round(json.load(open(f))["conv_igemm"]["hbm_bytes_per_launch"])
-            traffic_src = os.path.relpath(f, ROOT)
+            pj = json.load(open(f))
+            traffic = round(pj["conv_igemm"]["hbm_bytes_per_launch"])
+            # the summary names the kernel sources it was measured on (scripts/summarize_pmc.py): a summary older than the kernels says so here
+            traffic_src = {"file": os.path.relpath(f, ROOT), "measured_on_kernel_src_sha1": pj.get("_kernel_src_sha1"), "measured_at": pj.get("_measured_at")}
+            traffic_fresh = pj.get("_kernel_src_sha1") == kernel_source_sha1()
         except Exception:
             pass
         roof = {"bound": "mfma", "kernel": "conv_igemm256_kernel + conv_bwd_pair_kernel + conv_igemm512x128_kernel + conv_igemm_kernel (every fwd / dgrad conv launch; a dgrad launch that carries its layer's weight-gradient tiles counts their flops too)", "achieved": round(achieved, 1), "peak": peak,
-                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src, "traffic_matches_this_build": traffic_fresh,
                 "launches_per_step": n_launch // a.steps, "event_samples": len(prof),
                 "avg_launch_ms": round(tot_ms / n_launch, 4), "avg_launch_gflop": round(tot_fl / n_launch / 1e9, 2),
                 "whole_step_frac": round(conv_flops_model() * a.batch / (ms * 1e-3) / 1e12 / peak, 4)}
@@ -268,6 +363,11 @@ def main():
                                         "loss": float(plosses["loss"])})
             del ptrainer, pmodel
             torch.cuda.empty_cache()
+    # ---- the rest of the north star's evidence, rank 0 at N=1 only, after the training measurement: the similarity kernels against the HBM
+    #      roof and BASELINE config 5's inference geometry
+    if rank == 0 and world == 1 and not a.no_extras:
+        line["similarity"] = similarity_section(dev)
+        line["infer_mode"] = infer_section(dev)
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(tuple(int(x) for x in a.cpu_baseline_n.split(",")))

@@ -70,7 +70,7 @@ typedef struct wseg_conv_desc {
   int32_t relu_lt;     /* epi 0: ReLU on `out` channels < relu_lt (fused head: f_proj | cam); 0 = none */
   int32_t bm_hint;     /* 0 = library chooses the tile (64 / 128 pixel rows x 128 channels, or the 256 x 256 phase-pipelined
                           bf16 kernel for large layers with OC % 256 == 0, or the 512 x 128 one for OC = 128 layers with many pixels);
-                          64 / 128 / 224 / 256 = force; 257 / 259 = test hooks (row split, 512 x 128 tile); 258 and negative values: development
+                          64 / 128 / 224 / 256 = force; 259 = test hook (512 x 128 tile); negative values: development
                           probes, refused unless the library was built with -DWSEG_PROBES */
   /* optional SECOND row segment (the 128x128 view batched behind the 448x448 view in one launch): rows
    * [0, N*OH*OW) use (IH,IW,OH,OW); rows beyond use (IH2,IW2,OH2,OW2), same N, their input pixels follow the

@@ -121,7 +121,9 @@ def net_forward(x, sd, masks=None, return_lowres=False, gates=None):
     f_proj = _relu(F.conv2d(fea, sd["fc_proj.weight"]), gates, "f_proj")
     cam_low = F.conv2d(fea, sd["fc8.weight"])
     n, c, h, w = cam_low.size()
-    cam_d_norm = cam_normalize(cam_low)
+    # (gates["cam_d_norm"]: ANOTHER implementation's gated, normalised CAM — the no_grad input of the PCM, resnet38_contrast.py:41-48 — in place of
+    #  this one's: its arg-max gate is discontinuous, so a forward that differs by rounding picks other survivors)
+    cam_d_norm = gates["cam_d_norm"] if (gates is not None and "cam_d_norm" in gates) else cam_normalize(cam_low)
     f8_3 = _relu(F.conv2d(d["conv4"].detach(), sd["f8_3.weight"]), gates, "f8_3")
     f8_4 = _relu(F.conv2d(d["conv5"].detach(), sd["f8_4.weight"]), gates, "f8_4")
     x_s = F.interpolate(x, (h, w), mode="bilinear", align_corners=True)

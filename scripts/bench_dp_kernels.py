@@ -39,7 +39,7 @@ def main():
         y = torch.where(torch.rand(world, P, generator=g) < 0.45, torch.zeros(world, P), torch.randint(1, 21, (world, P), generator=g).float() % 3 * 5 + 2)
         rec = torch.empty(world, 2, 3, P)
         for v in range(2):
-            rec[:, v, 0] = y.int().view(torch.float32) if False else torch.tensor(y.int().numpy().view("float32"))
+            rec[:, v, 0] = y.int().view(torch.float32)
             rec[:, v, 1] = torch.rand(world, P, generator=g) * 0.8 + 0.2
             rec[:, v, 2] = torch.rand(world, P, generator=g)
         rec = rec.to(dev)

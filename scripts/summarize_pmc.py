@@ -12,8 +12,12 @@ for 16-B-per-lane stores and float atomics.  Calibration: `sgd` must come out at
 """
 import collections
 import csv
+import datetime
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 FAMILIES = [("conv_bwd_pair", "conv_bwd_pair"), ("conv_igemm256", "conv_igemm256"), ("conv_igemm512", "conv_igemm512"), ("conv_igemm_kernel", "conv_igemm128"), ("conv_wgrad", "conv_wgrad"),
             ("sgd_kernel", "sgd"), ("stem_kernel", "stem"), ("pcm_", "pcm"), ("nce_", "nce"), ("up_", "maps"),
@@ -45,6 +49,9 @@ def main():
     res = {"_note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `bench.py --steps 3 --warmup 1`; bytes = "
                     "counter*1024; FETCH doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of wide coalesced reads); "
                     "calibration: sgd = 3 reads + 2(+1 bf16 mirror) writes of the 420 MB flat buffers"}
+    from bench import kernel_source_sha1                    # the kernels this traffic belongs to: bench.py flags a summary older than its kernels
+    res["_kernel_src_sha1"] = kernel_source_sha1()
+    res["_measured_at"] = datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ")
     conv = [0, 0.0, 0.0]
     for fam in sorted(set(fa) | set(wa)):
         n = max(fa[fam][0], wa[fam][0])
@@ -59,7 +66,7 @@ def main():
                              "write_bytes_per_launch": conv[2] / conv[0], "hbm_bytes_per_launch": (conv[1] + conv[2]) / conv[0]}
     json.dump(res, open(out, "w"), indent=1)
     for k, v in res.items():
-        if k != "_note":
+        if not k.startswith("_"):
             print(f"{k:16s} launches {v['launches']:5d}  fetch {v['fetch_bytes_per_launch_corrected']/1e6:9.1f} MB  "
                   f"write {v['write_bytes_per_launch']/1e6:9.1f} MB  per launch")
 

@@ -90,13 +90,11 @@ def test_conv_fwd_dgrad_wgrad(case, dt, bm):
     assert np.abs(dwg.cpu().numpy() - 2 * ref).max() / scale < 2 * wtol
 
 
-@pytest.mark.parametrize("dt,OC,bm", [("f32", 128, 0), ("bf16", 128, 0), ("bf16", 256, 256), ("bf16", 256, 224), ("bf16", 128, 258), ("bf16", 128, 259)])
+@pytest.mark.parametrize("dt,OC,bm", [("f32", 128, 0), ("bf16", 128, 0), ("bf16", 256, 256), ("bf16", 256, 224), ("bf16", 128, 259)])
 def test_conv_epilogues(dt, OC, bm):
     """fused BN-ReLU-dropout second output (forward) and masked-scale (+residual) epilogue (backward);
     bm=256: the 256x256 phase-pipelined kernel (300 rows = one full + one partial row tile)."""
     from wseg_amd import _lib as L
-    if bm == 258 and not hasattr(L.lib, "wseg_gemm256_probe"):
-        pytest.skip("the 256x128 tile is a development probe (WSEG_PROBES=1 build only)")
     tdt = torch.float32 if dt == "f32" else torch.bfloat16
     N, H, W, IC, k = 2, 15, 10, 64, 3
     dev = "cuda"
@@ -260,18 +258,10 @@ def test_conv256_fwd_dgrad(case):
     y128 = torch.empty_like(yg)
     L.conv_igemm(xg, wf, y128, N=N, IH=H, IW=W, IC=IC, OH=OH, OW=OW, OC=OC, KH=k, KW=k, stride=s, dil=d, pad=pad, bm_hint=128)
     assert float((yg.float() - y128.float()).abs().max()) <= 2e-2
-    # row split (full rounds on the 256-tile kernel, remaining rows on the 128-tile kernel): 257 forces it at half the rows
-    ysp = torch.full_like(yg, float("nan"))
-    L.conv_igemm(xg, wf, ysp, N=N, IH=H, IW=W, IC=IC, OH=OH, OW=OW, OC=OC, KH=k, KW=k, stride=s, dil=d, pad=pad, bm_hint=257)
-    np.testing.assert_allclose(ysp.float().cpu().numpy(), _nhwc(y.detach()).numpy(), **tol)
     # 224-row tiles of the 256-tile kernel (each wave row owns 112 rows)
     y7 = torch.full_like(yg, float("nan"))
     L.conv_igemm(xg, wf, y7, N=N, IH=H, IW=W, IC=IC, OH=OH, OW=OW, OC=OC, KH=k, KW=k, stride=s, dil=d, pad=pad, bm_hint=224)
     np.testing.assert_allclose(y7.float().cpu().numpy(), _nhwc(y.detach()).numpy(), **tol)
-    if hasattr(L.lib, "wseg_gemm256_probe"):                    # the 256 x 128 tile kernel: development-probe builds only
-        y2n = torch.full_like(yg, float("nan"))
-        L.conv_igemm(xg, wf, y2n, N=N, IH=H, IW=W, IC=IC, OH=OH, OW=OW, OC=OC, KH=k, KW=k, stride=s, dil=d, pad=pad, bm_hint=258)
-        np.testing.assert_allclose(y2n.float().cpu().numpy(), _nhwc(y.detach()).numpy(), **tol)
     # the 512 x 128 tile kernel (four stacked A half-tiles, all 160 KiB of LDS)
     y5 = torch.full_like(yg, float("nan"))
     L.conv_igemm(xg, wf, y5, N=N, IH=H, IW=W, IC=IC, OH=OH, OW=OW, OC=OC, KH=k, KW=k, stride=s, dil=d, pad=pad, bm_hint=259)
@@ -404,7 +394,7 @@ def test_conv256_split_bf16(case):
     tol = dict(rtol=1e-4, atol=1e-4)
     y_ref = _nhwc(y.detach() + res).numpy()
     t_ref = _nhwc(torch.relu((y.detach() + res) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))).numpy()
-    for bm in (256, 224, 257, 128):
+    for bm in (256, 224, 128):
         yg = torch.full((N, OH, OW, OC), float("nan"), device=dev)
         tg = torch.full((N, OH, OW, OC), float("nan"), device=dev)
         L.conv_igemm(xg, wf, yg, tg, N=N, IH=H, IW=W, IC=IC, OH=OH, OW=OW, OC=OC, KH=k, KW=k, stride=s, dil=d, pad=pad, bm_hint=bm,

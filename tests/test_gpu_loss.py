@@ -217,6 +217,128 @@ def test_bf16_full_resolution_step(golden_dir, proc_sd):
             assert abs(float(got[k]) - ref) <= bars[k] * abs(ref), (name, k, float(got[k]), ref)
 
 
+# ---- the benchmarked mode (bf16) against what THE REFERENCE ITSELF shows in bf16 ------------------------------------------------------------
+# tests/golden/<name>_refbf16.npz (oracle/make_goldens.py `step_refbf16_golden`): the reference Net run with `model.bfloat16()` (weights and
+# activations bf16, loss maths f32) on the fixture's inputs.  Its deviation from its own fp32 run is the envelope of the storage precision: discrete
+# selections (CAM gate, pseudo-labels, top-32 members, ReLU decisions) flip under bf16 rounding in ANY implementation.  Per scalar, the envelope is
+# the reference's worst deviation over the three fixtures; the HIP bf16 mode must stay within ENVELOPE_FACTOR x of it on every fixture.  Per gradient
+# key group: cosine / norm-ratio DEFECT (1 - cos, |ratio - 1|) within the same factor of the reference's worst defect in that group.
+ENVELOPE_FIXTURES = ("step_S160_N2", "step_S448_N2", "step_S448_N2_b")
+ENVELOPE_FACTOR = 1.5
+
+
+def _grad_group(key):
+    if key.startswith(("f9.", "f8_3.", "f8_4.")):
+        return "pcm"
+    for k in ("fc8.", "fc_proj."):
+        if key.startswith(k):
+            return k
+    return "backbone"
+
+
+def _dev_of(scal, grads, gnorms, g):
+    """(per-scalar relative deviation, per-key (1 - cosine, |norm ratio - 1|)) of a run against the fp32 fixture g"""
+    ds = {k: abs(scal[k] - float(g["s/" + k])) / abs(float(g["s/" + k])) for k in SCALARS}
+    dg = {}
+    for k in GRAD_KEYS:
+        a, b = grads[k].astype(np.float64), g["gslice/" + k].astype(np.float64)
+        if not (np.isfinite(a).all() and np.isfinite(gnorms[k])):
+            continue                                     # (the reference's bf16 run overflows fc8's gradient at 448 x 448: no envelope from that key)
+        dg[k] = (1.0 - float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-300)), abs(gnorms[k] / float(g["gnorm/" + k]) - 1.0))
+    return ds, dg
+
+
+def test_bf16_within_the_reference_bf16_envelope(golden_dir, proc_sd):
+    from wseg_amd import synth
+    env_s = {k: 0.0 for k in SCALARS}
+    env_g = {}
+    ours = {}
+    for name in ENVELOPE_FIXTURES:
+        g = np.load(os.path.join(golden_dir, name + ".npz"))
+        rb = np.load(os.path.join(golden_dir, name + "_refbf16.npz"))
+        ds, dg = _dev_of({k: float(rb["s/" + k]) for k in SCALARS}, {k: rb["gslice/" + k] for k in GRAD_KEYS},
+                         {k: float(rb["gnorm/" + k]) for k in GRAD_KEYS}, g)
+        for k in SCALARS:
+            env_s[k] = max(env_s[k], ds[k])
+        for k, (c, r) in dg.items():
+            e = env_g.setdefault(_grad_group(k), [0.0, 0.0])
+            e[0], e[1] = max(e[0], c), max(e[1], r)
+        n, size, seed, py_seed = int(g["n"]), int(g["size"]), int(g["seed"]), int(g["py_seed"])
+        model, opt, tr = _trainer(proc_sd, "bf16", "hip", n, seed, py_seed)
+        got = tr.step(synth.synthetic_images(n, size, seed).cuda(), synth.synthetic_labels(n, seed).cuda())
+        params = dict(model.named_parameters())
+        gs, gn = {}, {}
+        for k in GRAD_KEYS:
+            flat = params[k].grad.detach().cpu().reshape(-1)
+            gs[k] = flat[::max(1, flat.numel() // 4096)][:4096].numpy()
+            gn[k] = float(params[k].grad.double().norm())
+        ours[name] = _dev_of({k: float(got[k]) for k in SCALARS}, gs, gn, g)
+    worst = {}
+    for name, (ds, dg) in ours.items():
+        for k in SCALARS:
+            worst[k] = max(worst.get(k, 0.0), ds[k] / env_s[k])
+            assert ds[k] <= ENVELOPE_FACTOR * env_s[k], (name, k, ds[k], env_s[k])
+        for k, (c, r) in dg.items():
+            ec, er = env_g[_grad_group(k)]
+            worst["cos:" + _grad_group(k)] = max(worst.get("cos:" + _grad_group(k), 0.0), c / ec)
+            worst["norm:" + _grad_group(k)] = max(worst.get("norm:" + _grad_group(k), 0.0), r / er)
+            assert c <= ENVELOPE_FACTOR * ec, (name, k, "1 - cos", c, ec)
+            assert r <= ENVELOPE_FACTOR * er + 2e-3, (name, k, "|norm ratio - 1|", r, er)
+    print("HIP bf16 deviation / reference-bf16 envelope (worst over fixtures):", {k: round(v, 3) for k, v in worst.items()})
+    print("envelope:", {k: float("%.3g" % v) for k, v in env_s.items()}, {k: [float("%.3g" % x) for x in v] for k, v in env_g.items()})
+
+
+# ... and the ARITHMETIC of the bf16 mode held tight: the CPU oracle (f32) re-run with the bf16 path's own discrete decisions — every ReLU site, the
+# gated CAM that enters the PCM, pseudo-labels and prototypes — must agree with the bf16 step to bf16-rounding size; what is left of the distance to the
+# reference fixture above is then flips of those decisions, not arithmetic (a bug in e.g. the bf16 PCM backward would show here, not hide in a 0.5 bar).
+BF16_INJECTED_SCALAR_BAR = 1.0e-2      # relative; measured worst 3.1e-3 (loss_ecr) — see the test's printed line
+BF16_INJECTED_COS_BAR = {"fc8.": 0.9995, "fc_proj.": 0.995, "pcm": 0.98, "backbone": 0.985}
+BF16_INJECTED_NORM_BAR = 0.03
+
+
+@pytest.mark.parametrize("name", ["step_S160_N2", "step_S128_N3"])
+def test_bf16_arithmetic_under_its_own_decisions(golden_dir, proc_sd, name):
+    from oracle import loss as oloss
+    from oracle import net as onet
+    from wseg_amd import synth
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    n, size, seed, py_seed = int(g["n"]), int(g["size"]), int(g["seed"]), int(g["py_seed"])
+    model, opt, tr = _trainer(proc_sd, "bf16", "hip", n, seed, py_seed)
+    eng = model._engine
+    eng.capture_ctx = True
+    img, lab = synth.synthetic_images(n, size, seed), synth.synthetic_labels(n, seed)
+    got = tr.step(img.cuda(), lab.cuda())
+    S = eng.last_ctx
+    gates = gates_from_ctx(S)
+    for vi, vw in enumerate(S["views"]):                 # the gated, normalised CAM the HIP forward fed its PCM (rows [pixels][32], 21 used)
+        h, w, off = vw["h"], vw["w"], vw["off"]
+        gates[vi]["cam_d_norm"] = S["G"][off:off + n * h * w, :21].float().view(n, h, w, 21).permute(0, 3, 1, 2).contiguous().cpu()
+    v1, v2 = eng.last_loss_views
+    inject = dict(protos1=v1.protos.cpu(), protos2=v2.protos.cpu(), pseudo1=v1.y.cpu().long(), pseudo2=v2.y.cpu().long())
+    eng.capture_ctx, eng.last_ctx, eng.last_loss_views = False, None, None
+    sd = {k: v.clone() for k, v in proc_sd.items()}
+    for k in onet.trainable_keys(sd):
+        sd[k].requires_grad_(True)
+    ref = oloss.train_step(img, lab, sd, synth.synthetic_dropout_masks(n, seed * 2), synth.synthetic_dropout_masks(n, seed * 2 + 1),
+                           0.20, random.Random(py_seed), gates1=gates[0], gates2=gates[1], inject=inject)
+    ref["loss"].backward()
+    meas = {}
+    for k in SCALARS:
+        meas[k] = abs(float(got[k]) - float(ref[k])) / abs(float(ref[k]))
+        assert meas[k] <= BF16_INJECTED_SCALAR_BAR, (k, float(got[k]), float(ref[k]))
+    params = dict(model.named_parameters())
+    for k in GRAD_KEYS:
+        a = params[k].grad.detach().cpu().reshape(-1).double()
+        b = sd[k].grad.reshape(-1).double()
+        cos = float(a @ b / (a.norm() * b.norm() + 1e-300))
+        ratio = float(a.norm() / b.norm())
+        meas["cos:" + k] = cos
+        meas["norm:" + k] = ratio
+        assert cos >= BF16_INJECTED_COS_BAR[_grad_group(k)], (k, cos)
+        assert abs(ratio - 1.0) <= BF16_INJECTED_NORM_BAR, (k, ratio)
+    print(f"{name} [bf16 vs the oracle under its own decisions]:", {k: float("%.4g" % v) for k, v in meas.items()})
+
+
 def _multistep(proc_sd, g, prec, loss_impl="hip"):
     """The 3-step fixture's protocol on the HIP path; returns ([per-step scalar dict], {key: relative error of the weight
     DELTA w_after - w_before on the fixture's 4096-sample slice})."""

@@ -107,3 +107,27 @@ def state_dict_spec():
     for hname, (co, ci) in HEAD_CONVS.items():
         spec[hname + ".weight"] = (co, ci, 1, 1)
     return spec
+
+
+def _osz(h, k, s, d):
+    p = d * (k // 2)
+    return (h + 2 * p - d * (k - 1) - 1) // s + 1
+
+
+def forward_macs(H, W):
+    """Algorithmic multiply-accumulates of ONE Net.forward on an H x W image (conv MACs = Cin * Cout * k^2 * h_out * w_out
+    for every conv of resnet38d.py:160-189 and resnet38_contrast.py:34-54, PCM = hw^2 * (192 + 21), resnet38_contrast.py:70-73).
+    448 x 448 -> 403.697e9, 128 x 128 -> 32.798e9."""
+    macs = 3 * 64 * 9 * H * W                                   # conv1a, stride 1, same size
+    h, w = H, W
+    for b in BLOCKS:
+        name, kind, cin, mid, cout, stride, fd, d, p = b
+        k0, d0 = (3, fd) if kind == "res" else (1, 1)
+        oh, ow = _osz(h, k0, stride, d0), _osz(w, k0, stride, d0)
+        for (_n, ci, co, k, s, dd) in block_convs(b):
+            macs += ci * co * k * k * oh * ow                   # every conv of a block produces the block's output size
+        h, w = oh, ow
+    hw = h * w
+    macs += hw * sum(co * ci for (co, ci) in HEAD_CONVS.values())
+    macs += hw * hw * (192 + 21)
+    return macs

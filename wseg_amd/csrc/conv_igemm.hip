@@ -39,7 +39,6 @@ struct Args {
   int ntn;          // column tiles
   int nwg;
   int row0;         // first output row (pixel) of this launch (a launch may cover a row sub-range)
-  int early_b;      // 256-tile kernel: weight DMA of the first two K-tiles issued before the row decode
   int perm;         // 256-tile kernel, stride-2 dgrad: rows are taken in PARITY-CLASS order (see perm_decode)
   int Q1, Q2;       // rows per parity class in segment 1 / 2 (= N * OH/2 * OW/2)
 };
@@ -567,12 +566,12 @@ constexpr int HALF256 = 16384, TILE256 = 4 * HALF256;
 // b[0] / b[1] that hold the two K halves in bf16 mode hold (hi, lo) here, and a quadrant issues lo.hi + hi.lo + hi.hi.
 // The tile body is a device function of (arguments, the workgroup's 128 KiB LDS buffer, block id): `conv_igemm256_kernel` is one workgroup = one
 // tile; `conv_bwd_pair_kernel` (below) runs it in the first workgroups of a grid whose other workgroups run the weight-gradient tile body.
-template <int EPI, int STG, int NI = 8, int DT = WSEG_BF16>
+template <int EPI, int NI = 8, int DT = WSEG_BF16>
 __device__ __forceinline__ void conv_igemm256_tile(const Args& a, char* smem, const int bid) {
   constexpr bool X3 = DT == WSEG_F32X3;
   constexpr int ES = X3 ? 4 : 2, CH = 16 / ES;
   constexpr int RH = NI * 16, BMT = 2 * RH;        // rows per wave row / per tile
-  static_assert(NI == 8 || (NI == 7 && STG >= 2), "224-row tiles exist for the 2-phase schedules only");
+  static_assert(NI == 8 || NI == 7, "256- or 224-row tiles");
   const wseg_conv_desc& d = a.d;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -626,10 +625,8 @@ __device__ __forceinline__ void conv_igemm256_tile(const Args& a, char* smem, co
   // The weight tiles need no pixel geometry: their LDS-DMA is issued BEFORE the row decode (three integer divisions per row)
   // and the tap set-up, which then run in the shadow of the DMA latency instead of in front of it.
   const int nt = d.in2 != nullptr ? (ntaps - 1) * a.cpt + a.cpt2 : ntaps * a.cpt;
-  if (a.early_b) {
-    issue_b(0, 0); issue_b(1, 0); advance_b();
-    if (nt > 1) { issue_b(0, 1); issue_b(1, 1); advance_b(); }
-  }
+  issue_b(0, 0); issue_b(1, 0); advance_b();
+  if (nt > 1) { issue_b(0, 1); issue_b(1, 1); advance_b(); }
   int a_base[4], a_yx[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -694,10 +691,6 @@ __device__ __forceinline__ void conv_igemm256_tile(const Args& a, char* smem, co
   // prologue: tile 0's A halves (B(0), B(1) are already in flight); everything must have landed before the first reads
   set_tap((int)(tl & 15ull));
   issue_a(0, 0); issue_a(1, 0); advance_a();
-  if (!a.early_b) {                                // (A/B switch WSEG_CONV_EARLYB=0: weights after the row decode, as before)
-    issue_b(0, 0); issue_b(1, 0); advance_b();
-    if (nt > 1) { issue_b(0, 1); issue_b(1, 1); advance_b(); }
-  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
@@ -750,91 +743,32 @@ __device__ __forceinline__ void conv_igemm256_tile(const Args& a, char* smem, co
     __builtin_amdgcn_s_setprio(0);                                                                           \
   } while (0)
 
-  if constexpr (STG == 0) {
-    for (int u = 0; u < nt; ++u) {
-      const int b = u & 1;
-      const char* aH = smem + b * TILE256 + wr * HALF256;
-      const char* bH = smem + b * TILE256 + (2 + (wc >> 1)) * HALF256;
-      // ---- p1: quadrant (0,0)
-      ldA(aH, 0); ldB(bH, 0, b0);
-      if (u + 1 < nt) issue_a(0, b ^ 1);
-      MFMA_Q(0, 0, b0);
-      __builtin_amdgcn_s_barrier();
-      // ---- p2: quadrant (0,1)
-      ldB(bH, 1, b1);
-      if (u + 1 < nt) { issue_a(1, b ^ 1); advance_a(); }
-      MFMA_Q(0, 1, b1);
-      __builtin_amdgcn_s_barrier();
-      // ---- p3: quadrant (1,1)
-      ldA(aH, 1);
-      if (u + 2 < nt) issue_b(0, b);
-      MFMA_Q(1, 1, b1);
-      __builtin_amdgcn_s_barrier();
-      // ---- p4: quadrant (1,0); the counted wait publishes tile u+1 (only B0/B1(u+2) may stay in flight)
-      if (u + 2 < nt) { issue_b(1, b); advance_b(); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      MFMA_Q(1, 0, b0);
-      __builtin_amdgcn_s_barrier();
-    }
-  } else if constexpr (STG == 1) {
-    // Ping-pong schedule: the two waves of every SIMD (wave w and w+4 = the two M halves, wr = 0 / 1) run HALF A PHASE
-    // apart.  Every phase is split into a read slot (fragment ds_reads, LDS-DMA issue, address work) and an MFMA slot
-    // (16 MFMAs) with a barrier after each; waves 4-7 start one slot late, so while one wave of a SIMD feeds the matrix
-    // pipe the other one does its reads — the LDS latency and the VALU work that the lock-step schedule exposes before
-    // every MFMA burst are hidden.  Slot refills are unchanged (A(u+1) in R1/R2, B(u+2) in R3/R4): a slot's last reader
-    // is the late group's read slot, one barrier before the early group's next issue into it.  Every wave executes
-    // 8 barriers per K-tile plus ONE extra (late group: before the loop, early group: after it), so the counts match.
+  {
+    // TWO phases of 32 MFMAs per K-tile (rows 0-63 then 64-127 of the wave tile, both B fragments read in phase 1 and kept), each a read
+    // slot (fragment ds_reads, LDS-DMA issue, address work) and an MFMA slot with a raw barrier after each.  PING-PONG: the two waves of every
+    // SIMD (wave w and w + 4 = the two M halves) run one slot apart — while one feeds the matrix pipe the other does its reads; every wave executes
+    // the same number of barriers (waves 4-7 one extra before the loop, waves 0-3 one after).  Measured alternatives (4 phases of 16 MFMAs,
+    // lock-step forms): profiles/HISTORY.md.
     if (wr == 1) __builtin_amdgcn_s_barrier();
-    for (int u = 0; u < nt; ++u) {
-      const int b = u & 1;
-      const char* aH = smem + b * TILE256 + wr * HALF256;
-      const char* bH = smem + b * TILE256 + (2 + (wc >> 1)) * HALF256;
-      ldA(aH, 0); ldB(bH, 0, b0);
-      if (u + 1 < nt) issue_a(0, b ^ 1);
-      __builtin_amdgcn_s_barrier();
-      MFMA_Q(0, 0, b0);
-      __builtin_amdgcn_s_barrier();
-      ldB(bH, 1, b1);
-      if (u + 1 < nt) { issue_a(1, b ^ 1); advance_a(); }
-      __builtin_amdgcn_s_barrier();
-      MFMA_Q(0, 1, b1);
-      __builtin_amdgcn_s_barrier();
-      ldA(aH, 1);
-      if (u + 2 < nt) issue_b(0, b);
-      __builtin_amdgcn_s_barrier();
-      MFMA_Q(1, 1, b1);
-      __builtin_amdgcn_s_barrier();
-      if (u + 2 < nt) { issue_b(1, b); advance_b(); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      MFMA_Q(1, 0, b0);
-      __builtin_amdgcn_s_barrier();
-    }
-    if (wr == 0) __builtin_amdgcn_s_barrier();
-  } else {
-    // STG 2 / 3: TWO phases of 32 MFMAs per K-tile (rows 0-63 then 64-127 of the wave tile, both B fragments read in
-    // phase 1 and kept): half the barriers.  2 = ping-pong (waves 4-7 one slot behind), 3 = lock-step.
-    constexpr bool stg = STG == 2;
-    if (stg && wr == 1) __builtin_amdgcn_s_barrier();
     for (int u = 0; u < nt; ++u) {
       const int b = u & 1;
       const char* aH = smem + b * TILE256 + wr * HALF256;
       const char* bH = smem + b * TILE256 + (2 + (wc >> 1)) * HALF256;
       ldA(aH, 0); ldB(bH, 0, b0); ldB(bH, 1, b1);
       if (u + 1 < nt) { issue_a(0, b ^ 1); issue_a(1, b ^ 1); advance_a(); }
-      if (stg) __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_barrier();
       MFMA_Q(0, 0, b0);
       MFMA_Q(0, 1, b1);
       __builtin_amdgcn_s_barrier();
       ldA(aH, 1);
       if (u + 2 < nt) { issue_b(0, b); issue_b(1, b); advance_b(); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (stg) __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_barrier();
       MFMA_Q(1, 1, b1);
       MFMA_Q(1, 0, b0);
       __builtin_amdgcn_s_barrier();
     }
-    if (stg && wr == 0) __builtin_amdgcn_s_barrier();
+    if (wr == 0) __builtin_amdgcn_s_barrier();
   }
 #undef MFMA_Q
 
@@ -843,198 +777,14 @@ __device__ __forceinline__ void conv_igemm256_tile(const Args& a, char* smem, co
   wave_local_epilogue<EPI, NI, DT>(a, smem, wid, lane, m0 + wr * RH, wc * 64, n0, acc);
 }
 
-template <int EPI, int STG, int NI = 8, int DT = WSEG_BF16>
+template <int EPI, int NI = 8, int DT = WSEG_BF16>
 __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const Args a) {
   __shared__ __attribute__((aligned(16))) char smem[2 * TILE256];
-  conv_igemm256_tile<EPI, STG, NI, DT>(a, smem, blockIdx.x);
+  conv_igemm256_tile<EPI, NI, DT>(a, smem, blockIdx.x);
 }
 
 
 
-#ifdef WSEG_PROBES   // measured dead end, kept for A/B runs only: built by `WSEG_PROBES=1 bash build.sh`
-// ---- 256(M) x 128(N) bf16 phase-pipelined variant: layers with OC = 128 (the frozen 224x224 prefix) and narrow tails.
-// 8 waves as 4(M) x 2(N), wave tile 64 x 64 = 4 x 4 accumulators; LDS = 3 K-tiles x {A0, A1, B} slots of
-// [128 rows][128 B] = 16 KiB each (144 KiB).  A K-tile is 2 phases of 16 MFMAs (32 rows x 64 cols of the wave tile each;
-// the B fragments of phase A are kept in registers for phase B):
-//     pA(u): A0(u+1), A1(u+1)      pB(u): B(u+2), counted s_waitcnt vmcnt(2)
-// 85 FLOP per filled byte (the 128^2 kernel: 64) and one barrier per 16 MFMAs, as in the 256^2 kernel.
-constexpr int TILE2N = 3 * HALF256;
-
-template <int EPI>
-__global__ __launch_bounds__(512, 2) void conv_igemm256x128_kernel(const Args a) {
-  constexpr int ES = 2, CH = 8;
-  __shared__ __attribute__((aligned(16))) char smem[3 * TILE2N];   // THREE K-tile buffers (144 KiB): see the loop
-  const wseg_conv_desc& d = a.d;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tile = xcd_remap(blockIdx.x, a.nwg);
-  const int tm = tile / a.ntn, tn = tile - tm * a.ntn;
-  const int m0 = a.row0 + tm * 256, n0 = tn * 128;
-  const int wr = wid >> 1, wc = wid & 1;
-  const int frow = lane & 15, fk = lane >> 4, sw = (lane >> 1) & 7;
-
-  const char* zero = reinterpret_cast<const char*>(g_wseg_zero_page);
-  const char* IN = reinterpret_cast<const char*>(d.in);
-  const char* Wp = reinterpret_cast<const char*>(d.w);
-
-  // staging: thread -> rows r0 + 64*j (j = 0..3) of the A tile, rows r0, r0 + 64 of the B tile (see the 256^2 kernel).
-  // These narrow layers change tap every 1-4 K-tiles (IC = 64..256) with only 32 MFMAs per wave per K-tile, so the per-tap
-  // address work must be small or the loop is VALU-issue bound: the gather address is  row pointer (per row, computed once,
-  // possibly outside the tensor) + tap offset (two scalars per tap, one per row segment), and the validity test is two
-  // unsigned compares on (iy0 + dy, ix0 + dx) — branch-free, ~16 vector instructions per row.  (fast_tap: every case except
-  // the stride-2 data gradient, which keeps the generic divisibility logic.)
-  const int r0 = tid >> 3, pch = tid & 7;
-  const int lc = pch ^ ((r0 >> 1) & 7);
-  const char* zsrc = zero + pch * 16;
-  const char* INl = IN + lc * 16;
-  const bool fast_tap = d.mode == 0 || d.stride == 1;
-  int a_base[4], a_yx[4];
-  const char* rowptr[4];
-  int a_iy0[4], a_ix0[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int m = m0 + r0 + 64 * j;
-    rowptr[j] = zsrc; a_iy0[j] = -0x2000; a_ix0[j] = -0x2000;       // (rows beyond M: never in bounds)
-    if (m < a.M) {
-      const wseg_rowgeo rg = wseg_decode_row(d, m);
-      int iy0, ix0;
-      if (d.mode == 0) { iy0 = rg.oy * d.stride - d.pad; ix0 = rg.ox * d.stride - d.pad; }
-      else             { iy0 = rg.oy + d.pad;            ix0 = rg.ox + d.pad; }
-      a_base[j] = (int)rg.in_base;
-      a_yx[j] = (rg.n_glob >= d.N ? (int)0x80000000 : 0) | ((iy0 + 0x2000) << 16) | (ix0 + 0x2000);
-      a_iy0[j] = iy0; a_ix0[j] = ix0;
-      rowptr[j] = INl + ((long)rg.in_base + (long)iy0 * rg.IW + ix0) * d.ld_in * ES;
-    } else {
-      a_base[j] = -1; a_yx[j] = (0x2000 << 16) | 0x2000;
-    }
-  }
-  const char* aptr[4];
-  unsigned a_live = 0;
-  const char* bptr = Wp + ((size_t)(n0 + r0) * a.taps * d.IC + (size_t)lc * CH) * ES;   // OC % 128 == 0 (host-checked)
-  const int brs = 64 * a.taps * d.IC * ES;
-  auto set_tap = [&](int tap) {
-    const int ky = tap / d.KW, kx = tap - ky * d.KW;
-    a_live = 0;
-    if (fast_tap) {
-      const int dyt = d.mode == 0 ? ky * d.dil : -ky * d.dil, dxt = d.mode == 0 ? kx * d.dil : -kx * d.dil;   // (uniform)
-      const long off1 = ((long)dyt * d.IW + dxt) * d.ld_in * ES, off2 = ((long)dyt * d.IW2 + dxt) * d.ld_in * ES;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const bool s2 = a_yx[j] < 0;
-        const unsigned H = s2 ? d.IH2 : d.IH, W = s2 ? d.IW2 : d.IW;
-        const bool ok = (unsigned)(a_iy0[j] + dyt) < H && (unsigned)(a_ix0[j] + dxt) < W;
-        const char* p = rowptr[j] + (s2 ? off2 : off1);
-        aptr[j] = ok ? p : zsrc;
-        a_live |= ok ? 1u << j : 0u;
-      }
-      return;
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int iy0 = ((a_yx[j] >> 16) & 0x7FFF) - 0x2000, ix0 = (a_yx[j] & 0xFFFF) - 0x2000;
-      const bool s2 = a_yx[j] < 0;
-      const int H = s2 ? d.IH2 : d.IH, W = s2 ? d.IW2 : d.IW;
-      int iy, ix; bool ok = a_base[j] >= 0;
-      if (d.mode == 0) {
-        iy = iy0 + ky * d.dil; ix = ix0 + kx * d.dil;
-      } else {
-        const int ty = iy0 - ky * d.dil, tx = ix0 - kx * d.dil;
-        ok = ok && ty >= 0 && tx >= 0;
-        if (d.stride == 1) { iy = ty; ix = tx; }
-        else { iy = ty / d.stride; ix = tx / d.stride; ok = ok && (iy * d.stride == ty) && (ix * d.stride == tx); }
-      }
-      ok = ok && iy >= 0 && iy < H && ix >= 0 && ix < W;
-      if (ok) { aptr[j] = INl + (size_t)(a_base[j] + iy * W + ix) * d.ld_in * ES; a_live |= 1u << j; }
-      else    { aptr[j] = zsrc; }
-    }
-  };
-  int a_tap = 0, a_cc = 0;
-  auto issue_a = [&](int buf) {                    // both halves of the NEXT A tile (4 pieces), then advance
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      char* dst = smem + buf * TILE2N + h * HALF256 + wid * 1024;
-      glds16(aptr[2 * h], dst);
-      glds16(aptr[2 * h + 1], dst + 8192);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) aptr[j] += ((a_live >> j) & 1u) << 7;
-    if (++a_cc == a.cpt) { a_cc = 0; if (++a_tap < a.taps) set_tap(a_tap); }
-  };
-  auto issue_b = [&](int buf) {                    // the NEXT B tile (2 pieces), then advance
-    char* dst = smem + buf * TILE2N + 2 * HALF256 + wid * 1024;
-    glds16(bptr, dst);
-    glds16(bptr + brs, dst + 8192);
-    bptr += 128;
-  };
-
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const int nt = a.taps * a.cpt;
-  // Three-buffer ring: A runs 2 tiles ahead, B 3 (its slot is free after phase A) — ~110 KiB of LDS-DMA in flight per CU.
-  // These OC = 128 layers stream their pixels from HBM (224x224 maps, little reuse per row), where a CU's DMA rate is set
-  // by latency x bytes in flight; with two buffers (72 KiB in flight) the kernel only matched the 128^2 kernel.
-  set_tap(0);
-  issue_a(0); issue_b(0);
-  if (nt > 1) { issue_a(1); issue_b(1); }
-  if (nt > 2) { issue_b(2); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
-  else if (nt > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-
-  bf16x8 af[2][2], bf[2][4];
-  auto ldA = [&](const char* aH, int ha) {
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-        af[ks][i] = *reinterpret_cast<const bf16x8*>(aH + ((wr & 1) * 64 + ha * 32 + i * 16 + frow) * 128 + (((ks * 4 + fk) ^ sw) << 4));
-  };
-#define MFMA_H(HA)                                                                                           \
-  do {                                                                                                       \
-    __builtin_amdgcn_s_setprio(1);                                                                           \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                         \
-      _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                          \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                        \
-          acc[(HA) * 2 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][i], bf[ks][j], acc[(HA) * 2 + i][j], 0, 0, 0); \
-    __builtin_amdgcn_s_setprio(0);                                                                           \
-  } while (0)
-
-  // (lock-step: with only 16 MFMAs per slot the ping-pong variant of this kernel measured 16 % SLOWER — 590 vs 703 TF/s on the
-  //  128->128 3x3 224x224 layers — the extra barriers cost more than the hidden read latency)
-  int b = 0, b2 = 2;                               // buffers of tile u and of tile u+2
-  for (int u = 0; u < nt; ++u) {
-    const char* aH = smem + b * TILE2N + (wr >> 1) * HALF256;
-    const char* bH = smem + b * TILE2N + 2 * HALF256;
-    // ---- pA: rows 0-31 of the wave tile; A(u+2) refills the buffer tile u-1 has left
-    ldA(aH, 0);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        bf[ks][j] = *reinterpret_cast<const bf16x8*>(bH + (wc * 64 + j * 16 + frow) * 128 + (((ks * 4 + fk) ^ sw) << 4));
-    if (u + 2 < nt) issue_a(b2);
-    MFMA_H(0);
-    __builtin_amdgcn_s_barrier();
-    // ---- pB: rows 32-63; B(u+3) refills this tile's own B slot (read in pA); the counted wait publishes tile u+1:
-    //      younger operations that may stay in flight = B(u+2), A(u+2) (2 + 4) and B(u+3) (2)
-    ldA(aH, 1);
-    if (u + 3 < nt) { issue_b(b); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
-    else if (u + 2 < nt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    MFMA_H(1);
-    __builtin_amdgcn_s_barrier();
-    b2 = b; b = b == 2 ? 0 : b + 1;                // (u+1) % 3 ; (u+3) % 3 == u % 3
-  }
-#undef MFMA_H
-
-  __syncthreads();                                 // every wave is done with the pipeline buffers
-  wave_local_epilogue<EPI, 4>(a, smem, wid, lane, m0 + wr * 64, wc * 64, n0, acc);
-}
-#endif  // WSEG_PROBES
 
 
 // ---- 512(M) x 128(N) bf16 phase-pipelined variant for OC = 128 layers (the frozen 224x224 prefix) -----------------------
@@ -1192,9 +942,9 @@ __global__ __launch_bounds__(512, 2) void conv_bwd_pair_kernel(const Args ad, co
   static_assert(2 * TILE256 == 2 * 4 * 16384, "both tile bodies use the same 128 KiB");
   const int b = blockIdx.x;
   if (b < nd_pad) {
-    if (b < ad.nwg) conv_igemm256_tile<EPI, 2, NI, WSEG_BF16>(ad, smem, b);
+    if (b < ad.nwg) conv_igemm256_tile<EPI, NI, WSEG_BF16>(ad, smem, b);
   } else {
-    wseg_wg::conv_wgrad_pipe_tile<2, UNIT>(aw, smem, b - nd_pad);
+    wseg_wg::conv_wgrad_pipe_tile<UNIT>(aw, smem, b - nd_pad);
   }
 }
 
@@ -1222,8 +972,10 @@ static int conv_validate(const wseg_conv_desc* d) {
   return 0;
 }
 
-// tile choice of the bf16 256-tile kernel (default switches): by CU time in units of (32 rows x 256 columns x K) at the 256-tile kernel's rate — a
-// round of NI-block tiles costs NI, a round of the 128^2 kernel (two resident workgroups of 2 units each, 0.75 of that rate) 5.33
+// ---- host side ------------------------------------------------------------------------------------------------------------
+// Tile choice by CU time in units of (32 rows x 256 columns x K) at the 256-tile kernel's rate: a round of NI-block tiles costs NI, a round of the
+// 128^2 kernel (two resident workgroups of 2 units each, 0.75 of that rate) 5.33.  Fitted on the training AND the inference geometries
+// (scripts/bench_conv_infer.py).
 static bool conv_cost_prefers_256(long M, int OC) {
   const long t256 = ((M + 255) / 256) * ((OC + 255) / 256);
   const long rounds = (t256 + 255) / 256;
@@ -1231,21 +983,21 @@ static bool conv_cost_prefers_256(long M, int OC) {
   const double c_big = std::min((double)rounds * 8.0, (double)((t224 + 255) / 256) * 7.0), c_128 = (double)((t128 + 511) / 512) * 5.33;
   return c_big <= c_128;
 }
+// 224-row tiles (NI = 7) when they need less CU time than 256-row tiles: rounds(tiles) x rows per tile
 static bool conv_rounds_prefer_224(long M, int ntn256) {
   const long t8 = ((M + 255) / 256) * ntn256, t7 = ((M + 223) / 224) * ntn256;
   return ((t7 + 255) / 256) * 7 < ((t8 + 255) / 256) * 8;
 }
 
-extern "C" int wseg_conv_igemm(const wseg_conv_desc* d, void* stream) {
-  if (int rc = conv_validate(d)) return rc;
+static long conv_rows(const wseg_conv_desc* d) { return (long)d->N * d->OH * d->OW + (long)d->N * d->OH2 * d->OW2; }
+
+// The common part of every launch's arguments (K walk, two-source form).  < 0: error.
+static int conv_fill_args(const wseg_conv_desc* d, Args& a) {
   const int es = d->dtype == WSEG_BF16 ? 2 : 4;
-  const long M = (long)d->N * d->OH * d->OW + (long)d->N * d->OH2 * d->OW2;
-  Args a;
   a.d = *d;
   a.perm = 0; a.Q1 = a.Q2 = 0;
-  static const int early_b = getenv("WSEG_CONV_EARLYB") ? atoi(getenv("WSEG_CONV_EARLYB")) : 1;
-  a.early_b = early_b;
-  a.M = (int)M;
+  a.M = (int)conv_rows(d);
+  a.row0 = 0;
   a.taps = d->KH * d->KW;
   if (d->in2) {                                    // two sources: the second one is an extra last "tap" of w = [OC][KH*KW*IC + IC2]
     WSEG_CHECK(d->KH == d->KW && (d->KH & 1) && d->KH * d->KW < 15 && d->stride == 1 && d->pad == d->dil * (d->KH / 2) &&
@@ -1259,10 +1011,50 @@ extern "C" int wseg_conv_igemm(const wseg_conv_desc* d, void* stream) {
   a.cpt2 = ic2 * es / ROWB;
   a.krow = d->in2 ? d->KH * d->KW * d->IC + ic2 : a.taps * d->IC;
   a.ntn = (d->OC + BN - 1) / BN;
+  return 0;
+}
+
+// Does this launch run on the 256-tile kernel, and with which tile height?  ONE function for wseg_conv_igemm and for wseg_conv_bwd_pair (the paired
+// grid must choose exactly what the stand-alone launch would).  On return (true): a.ntn / a.nwg / a.perm / a.Q* are set for the 256-tile kernel.
+static bool conv_plan_256(const wseg_conv_desc* d, Args& a, bool& ni7) {
+  const long M = a.M;
+  ni7 = false;
+  if (!((d->dtype == WSEG_BF16 || (d->dtype == WSEG_F32X3 && d->in2 == nullptr)) && d->OC % 256 == 0 && d->bm_hint != 64 && d->bm_hint != 128 &&
+        d->bm_hint != 259 && d->bm_hint >= 0))
+    return false;
+  static const int auto256 = getenv("WSEG_CONV256") ? atoi(getenv("WSEG_CONV256")) : 1;   // (0: A/B switch — 128-tile kernel everywhere)
+  if (!(d->bm_hint == 256 || d->bm_hint == 224 || d->in2 != nullptr || (auto256 && conv_cost_prefers_256(M, d->OC)))) return false;
+  if (!(d->IH <= 16384 && d->IW <= 16384 && d->OH <= 16384 && d->OW <= 16384 && d->pad <= 4096 &&
+        (long)d->N * d->IH * d->IW + (long)d->N * d->IH2 * d->IW2 < (1L << 31))) {
+    wseg_set_error("conv_igemm: shape too large for the 256-tile kernel");
+    a.nwg = -1;
+    return true;
+  }
+  static const int perm_ok = getenv("WSEG_CONV_PERM") ? atoi(getenv("WSEG_CONV_PERM")) : 1;
+  if (perm_ok && d->mode == 1 && d->stride == 2 && d->OH % 2 == 0 && d->OW % 2 == 0 && d->OH2 % 2 == 0 && d->OW2 % 2 == 0 && a.taps <= 9 &&
+      (a.taps > 1 || d->bm_hint == 256)) {   // (1x1: nothing to skip in the K loop, the per-vector row mapping only costs — measured)
+    a.perm = 1;
+    a.Q1 = d->N * (d->OH / 2) * (d->OW / 2);
+    a.Q2 = d->N * (d->OH2 / 2) * (d->OW2 / 2);
+  }
+  a.ntn = (d->OC + 255) / 256;
+  static const int auto224 = getenv("WSEG_CONV224") ? atoi(getenv("WSEG_CONV224")) : 1;   // (0: A/B switch; 2: always)
+  ni7 = d->bm_hint != 256 && (d->bm_hint == 224 || (auto224 && d->bm_hint == 0 && (auto224 == 2 || conv_rounds_prefer_224(M, a.ntn))));
+  const int bmt = ni7 ? 224 : 256;
+  a.nwg = (int)(((M + bmt - 1) / bmt) * a.ntn);
+  return true;
+}
+
+extern "C" int wseg_conv_igemm(const wseg_conv_desc* d, void* stream) {
+  if (int rc = conv_validate(d)) return rc;
+  const long M = conv_rows(d);
+  Args a;
+  if (int rc = conv_fill_args(d, a)) return rc;
   // few output pixels (view 2, 16x16 maps): 64-row tiles double the workgroup count
   const bool small = d->bm_hint == 64 || (d->bm_hint != 128 && ((M + 127) / 128) * a.ntn < 384 && M > 64);
   hipStream_t s = (hipStream_t)stream;
   WSEG_CHECK(d->out || d->epi == 0, "conv_igemm: epilogue %d needs `out`", d->epi);
+  WSEG_CHECK(d->bm_hint != 257 && d->bm_hint != 258 && d->bm_hint >= 0, "conv_igemm: bm_hint %d was a development hook and no longer exists", d->bm_hint);
 #define WSEG_LAUNCH_CONV1(DT_, EPI_, BM_) hipLaunchKernelGGL((conv_igemm_kernel<DT_, EPI_, BM_>), dim3(a.nwg), dim3(256), 0, s, a)
 #define WSEG_LAUNCH_CONV(BM_)                                                                                   \
   do {                                                                                                          \
@@ -1274,33 +1066,10 @@ extern "C" int wseg_conv_igemm(const wseg_conv_desc* d, void* stream) {
       if (d->epi == 0) WSEG_LAUNCH_CONV1(WSEG_F32, 0, BM_); else if (d->epi == 1) WSEG_LAUNCH_CONV1(WSEG_F32, 1, BM_); else WSEG_LAUNCH_CONV1(WSEG_F32, 2, BM_); \
     }                                                                                                           \
   } while (0)
-  a.row0 = 0;
-  // 256x256 phase-pipelined tiles (bf16, OC >= 256): chosen when the (1 workgroup / CU) rounds are full enough
-  bool big = false;
-  if ((d->dtype == WSEG_BF16 || (d->dtype == WSEG_F32X3 && d->in2 == nullptr)) && d->OC % 256 == 0 && d->bm_hint != 64 && d->bm_hint != 128 && d->bm_hint != 258 && d->bm_hint != 259 && d->bm_hint >= 0) {   // (257: test hook, forces the row split)
-    const long t256 = ((M + 255) / 256) * ((d->OC + 255) / 256);
-    const long rounds = (t256 + 255) / 256;
-    static const int auto256 = getenv("WSEG_CONV256") ? atoi(getenv("WSEG_CONV256")) : 1;   // (0: A/B switch)
-    static const int split_tail = getenv("WSEG_CONV_SPLIT") ? atoi(getenv("WSEG_CONV_SPLIT")) : 0;
-    // Tile choice by CU time in units of (32 rows x 256 columns x K) at the 256-tile kernel's rate: a round of NI-block tiles
-    // costs NI, a round of the 128^2 kernel (two resident workgroups of 2 units each, 0.75 of that rate) 5.33.  Fitted on the
-    // training AND the inference geometries (scripts/bench_conv_infer.py: 25 000-row launches ran 15-40 % faster on 224-row
-    // tiles than on the 128^2 kernel the previous rule — at least 200 tiles, last round 80 % full — gave them).
-    const long t224 = ((M + 223) / 224) * ((d->OC + 255) / 256), t128 = ((M + 127) / 128) * ((d->OC + 127) / 128);
-    const double c_big = std::min((double)rounds * 8.0, (double)((t224 + 255) / 256) * 7.0), c_128 = (double)((t128 + 511) / 512) * 5.33;
-    const bool by_cost = auto256 == 2 ? (t256 >= 200 && (double)t256 / (double)(rounds * 256) >= 0.80) : c_big <= c_128;
-    big = d->bm_hint == 256 || d->bm_hint == 257 || d->bm_hint == 224 || d->in2 != nullptr ||
-          (auto256 && (by_cost || (split_tail && d->bm_hint == 0 && t256 >= 256)));
-    if (big)
-      WSEG_CHECK(d->IH <= 16384 && d->IW <= 16384 && d->OH <= 16384 && d->OW <= 16384 && d->pad <= 4096 &&
-                 (long)d->N * d->IH * d->IW + (long)d->N * d->IH2 * d->IW2 < (1L << 31), "conv_igemm: shape too large for the 256-tile kernel");
-  }
-  // 256 x 128 phase-pipelined tiles (bm_hint 258, or WSEG_CONV256X128=1 for OC = 128 layers with many pixels).  Measured on
-  // the frozen 224x224 prefix (128->128 3x3, K = 1152): 703 vs 700 TF/s for the 128^2 kernel — those layers are bound by
-  // their epilogue (18 K-tiles per tile), which two resident workgroups per CU overlap and one cannot; off by default.
-#ifdef WSEG_PROBES
-  static const int auto2n = getenv("WSEG_CONV256X128") ? atoi(getenv("WSEG_CONV256X128")) : 0;
-#endif
+  // 256 x 256 (or 224 x 256) phase-pipelined tiles: bf16 / split-bf16, OC % 256 == 0, chosen by the CU-time model
+  bool ni7 = false;
+  const bool big = conv_plan_256(d, a, ni7);
+  if (big && a.nwg < 0) return -1;
   // 512 x 128 phase-pipelined tiles for OC = 128 layers with many pixels (259 forces it); fast taps only
   static const int auto512 = getenv("WSEG_CONV512") ? atoi(getenv("WSEG_CONV512")) : 1;   // (0: A/B switch; measured 649 -> 766 TF/s on 128->128 3x3 224^2)
   const bool tall = !big && d->dtype == WSEG_BF16 && d->OC % 128 == 0 && (d->mode == 0 || d->stride == 1) &&
@@ -1316,89 +1085,16 @@ extern "C" int wseg_conv_igemm(const wseg_conv_desc* d, void* stream) {
     WSEG_LAUNCH_CHECK();
     return 0;
   }
-#ifdef WSEG_PROBES
-  const bool mid = !big && d->dtype == WSEG_BF16 && d->OC % 128 == 0 &&
-                   (d->bm_hint == 258 || (auto2n && d->bm_hint == 0 && d->OC == 128 && (M + 255) / 256 >= 512));
-  if (mid) {
-    WSEG_CHECK(d->IH <= 16384 && d->IW <= 16384 && d->OH <= 16384 && d->OW <= 16384 && d->pad <= 4096 &&
-               (long)d->N * d->IH * d->IW + (long)d->N * d->IH2 * d->IW2 < (1L << 31), "conv_igemm: shape too large for the 256x128-tile kernel");
-    a.ntn = d->OC / 128;
-    a.nwg = (int)(((M + 255) / 256) * a.ntn);
-    if (d->epi == 0) hipLaunchKernelGGL(conv_igemm256x128_kernel<0>, dim3(a.nwg), dim3(512), 0, s, a);
-    else if (d->epi == 1) hipLaunchKernelGGL(conv_igemm256x128_kernel<1>, dim3(a.nwg), dim3(512), 0, s, a);
-    else hipLaunchKernelGGL(conv_igemm256x128_kernel<2>, dim3(a.nwg), dim3(512), 0, s, a);
-    WSEG_LAUNCH_CHECK();
-    return 0;
-  }
-#else
-  WSEG_CHECK(d->bm_hint != 258, "conv_igemm: bm_hint 258 (256x128 probe tile) needs a -DWSEG_PROBES build");
-#endif
   if (big) {
-    const int ntn128 = a.ntn;
-    static const int perm_ok = getenv("WSEG_CONV_PERM") ? atoi(getenv("WSEG_CONV_PERM")) : 1;
-    if (perm_ok && d->mode == 1 && d->stride == 2 && d->OH % 2 == 0 && d->OW % 2 == 0 && d->OH2 % 2 == 0 && d->OW2 % 2 == 0 && a.taps <= 9 &&
-        (a.taps > 1 || d->bm_hint == 256)) {   // (1x1: nothing to skip in the K loop, the per-vector row mapping only costs — measured)
-      a.perm = 1;
-      a.Q1 = d->N * (d->OH / 2) * (d->OW / 2);
-      a.Q2 = d->N * (d->OH2 / 2) * (d->OW2 / 2);
-    }
-    static const int stagger = getenv("WSEG_CONV_STAGGER") ? atoi(getenv("WSEG_CONV_STAGGER")) : 2;   // 0: 4 phases lock-step, 1: 4 phases ping-pong, 2: 2 phases ping-pong (best), 3: 2 phases lock-step
-    a.ntn = (d->OC + 255) / 256;
-    // 224-row tiles (NI = 7) when they need less CU time than 256-row tiles: rounds(tiles) x rows per tile
-    static const int auto224 = getenv("WSEG_CONV224") ? atoi(getenv("WSEG_CONV224")) : 1;   // (0: A/B switch)
-    const long t8 = ((M + 255) / 256) * a.ntn, t7 = ((M + 223) / 224) * a.ntn;
-    const bool ni7 = (stagger == 2 || stagger == 3) && d->bm_hint != 256 && d->bm_hint != 257 &&
-                     (d->bm_hint == 224 || (auto224 && d->bm_hint == 0 && (auto224 == 2 || ((t7 + 255) / 256) * 7 < ((t8 + 255) / 256) * 8)));
-    const int bmt = ni7 ? 224 : 256;
-    const long ntm = (M + bmt - 1) / bmt;
-    long main_tm = ntm;                              // row tiles given to the 256-tile kernel
-    // WSEG_CONV_SPLIT=1 (experiment, off): only the FULL rounds go to the 256-tile kernel and the remaining rows to the
-    // 128-tile kernel (quarter-size tiles, a shorter tail).  Measured: no gain (26.35 vs 26.55 ms/step of conv time,
-    // layers move +-8 % either way) — a partly filled last round runs faster per tile, rounds are not discrete here either.
-    static const int split_tail = getenv("WSEG_CONV_SPLIT") ? atoi(getenv("WSEG_CONV_SPLIT")) : 0;
-    const long t256 = ntm * a.ntn, full = t256 / 256, rem = t256 % 256;
-    if (!a.perm && !ni7 && ((split_tail && d->bm_hint == 0 && full >= 1 && rem > 0 && rem <= 208 && 256 % a.ntn == 0) || d->bm_hint == 257))
-      main_tm = d->bm_hint == 257 ? std::max(1L, ntm / 2) : full * 256 / a.ntn;
-    a.nwg = (int)(main_tm * a.ntn);
-#define WSEG_LAUNCH_256(STG_)                                                                                          \
-  do {                                                                                                                 \
-    if (d->epi == 0) hipLaunchKernelGGL((conv_igemm256_kernel<0, STG_>), dim3(a.nwg), dim3(512), 0, s, a);              \
-    else if (d->epi == 1) hipLaunchKernelGGL((conv_igemm256_kernel<1, STG_>), dim3(a.nwg), dim3(512), 0, s, a);         \
-    else hipLaunchKernelGGL((conv_igemm256_kernel<2, STG_>), dim3(a.nwg), dim3(512), 0, s, a);                          \
+#define WSEG_LAUNCH_256(NI_, DT_)                                                                                              \
+  do {                                                                                                                         \
+    if (d->epi == 0) hipLaunchKernelGGL((conv_igemm256_kernel<0, NI_, DT_>), dim3(a.nwg), dim3(512), 0, s, a);                  \
+    else if (d->epi == 1) hipLaunchKernelGGL((conv_igemm256_kernel<1, NI_, DT_>), dim3(a.nwg), dim3(512), 0, s, a);             \
+    else hipLaunchKernelGGL((conv_igemm256_kernel<2, NI_, DT_>), dim3(a.nwg), dim3(512), 0, s, a);                              \
   } while (0)
-    if (d->dtype == WSEG_F32X3) {                   // split-bf16 products: the 2-phase ping-pong schedule only
-#define WSEG_LAUNCH_256X3(NI_)                                                                                                          \
-  do {                                                                                                                                  \
-    if (d->epi == 0) hipLaunchKernelGGL((conv_igemm256_kernel<0, 2, NI_, WSEG_F32X3>), dim3(a.nwg), dim3(512), 0, s, a);                 \
-    else if (d->epi == 1) hipLaunchKernelGGL((conv_igemm256_kernel<1, 2, NI_, WSEG_F32X3>), dim3(a.nwg), dim3(512), 0, s, a);            \
-    else hipLaunchKernelGGL((conv_igemm256_kernel<2, 2, NI_, WSEG_F32X3>), dim3(a.nwg), dim3(512), 0, s, a);                             \
-  } while (0)
-      if (ni7) WSEG_LAUNCH_256X3(7); else WSEG_LAUNCH_256X3(8);
-#undef WSEG_LAUNCH_256X3
-    } else if (ni7) {
-      if (stagger == 2) {
-        if (d->epi == 0) hipLaunchKernelGGL((conv_igemm256_kernel<0, 2, 7>), dim3(a.nwg), dim3(512), 0, s, a);
-        else if (d->epi == 1) hipLaunchKernelGGL((conv_igemm256_kernel<1, 2, 7>), dim3(a.nwg), dim3(512), 0, s, a);
-        else hipLaunchKernelGGL((conv_igemm256_kernel<2, 2, 7>), dim3(a.nwg), dim3(512), 0, s, a);
-      } else {
-        if (d->epi == 0) hipLaunchKernelGGL((conv_igemm256_kernel<0, 3, 7>), dim3(a.nwg), dim3(512), 0, s, a);
-        else if (d->epi == 1) hipLaunchKernelGGL((conv_igemm256_kernel<1, 3, 7>), dim3(a.nwg), dim3(512), 0, s, a);
-        else hipLaunchKernelGGL((conv_igemm256_kernel<2, 3, 7>), dim3(a.nwg), dim3(512), 0, s, a);
-      }
-    } else if (stagger == 1) WSEG_LAUNCH_256(1);
-    else if (stagger == 2) WSEG_LAUNCH_256(2);
-    else if (stagger == 3) WSEG_LAUNCH_256(3);
-    else {
-      if (d->epi == 0) hipLaunchKernelGGL((conv_igemm256_kernel<0, 0>), dim3(a.nwg), dim3(512), 0, s, a);
-      else if (d->epi == 1) hipLaunchKernelGGL((conv_igemm256_kernel<1, 0>), dim3(a.nwg), dim3(512), 0, s, a);
-      else hipLaunchKernelGGL((conv_igemm256_kernel<2, 0>), dim3(a.nwg), dim3(512), 0, s, a);
-    }
-    if (main_tm < ntm) {
-      a.row0 = (int)(main_tm * 256);
-      a.ntn = ntn128;
-      a.nwg = (int)(((M - a.row0 + 127) / 128) * a.ntn);
-      WSEG_LAUNCH_CONV(128);
-    }
+    if (d->dtype == WSEG_F32X3) { if (ni7) WSEG_LAUNCH_256(7, WSEG_F32X3); else WSEG_LAUNCH_256(8, WSEG_F32X3); }
+    else { if (ni7) WSEG_LAUNCH_256(7, WSEG_BF16); else WSEG_LAUNCH_256(8, WSEG_BF16); }
+#undef WSEG_LAUNCH_256
   } else if (small) {
     a.nwg = (int)(((M + 63) / 64) * a.ntn);
     WSEG_LAUNCH_CONV(64);
@@ -1416,57 +1112,39 @@ extern "C" int wseg_conv_igemm(const wseg_conv_desc* d, void* stream) {
 
 // One launch for `dg` (a stride-1 bf16 data gradient on the 256-tile kernel) and `wg` (a bf16 weight gradient on the 256 x 256 phase-pipelined
 // kernel) when both qualify; otherwise the two ordinary launches, in that order.  Results are those of the separate launches.
-// 1: the pair qualifies for the joint grid (pl then holds the weight gradient's plan), 0: two launches, < 0: error
-static int conv_bwd_pair_plan(const wseg_conv_desc* dg, const wseg_wgrad_desc* wg, wseg_wg::Plan& pl) {
+// 1: the pair qualifies for the joint grid (a / ni7 / pl then hold both plans), 0: two launches, < 0: error
+static int conv_bwd_pair_plan(const wseg_conv_desc* dg, const wseg_wgrad_desc* wg, Args& a, bool& ni7, wseg_wg::Plan& pl) {
   WSEG_CHECK(dg && wg, "conv_bwd_pair: null descriptor");
   static const int pair_ok = getenv("WSEG_BWD_PAIR") ? atoi(getenv("WSEG_BWD_PAIR")) : 1;           // (0: A/B switch — two launches)
-  static const int stagger = getenv("WSEG_CONV_STAGGER") ? atoi(getenv("WSEG_CONV_STAGGER")) : 2;
-  static const int auto256 = getenv("WSEG_CONV256") ? atoi(getenv("WSEG_CONV256")) : 1;
-  static const int auto224 = getenv("WSEG_CONV224") ? atoi(getenv("WSEG_CONV224")) : 1;
-  const long M = (long)dg->N * dg->OH * dg->OW + (long)dg->N * dg->OH2 * dg->OW2;
-  const bool ok = pair_ok && stagger == 2 && auto256 == 1 && auto224 == 1 && dg->dtype == WSEG_BF16 && wg->dtype == WSEG_BF16 && dg->mode == 1 &&
-                  dg->stride == 1 && dg->bm_hint == 0 && dg->OC % 256 == 0 && dg->out != nullptr && dg->out2 == nullptr &&
-                  dg->epi >= 0 && dg->epi <= 2 && (dg->in2 != nullptr || conv_cost_prefers_256(M, dg->OC)) &&      // (two sources: always the 256-tile kernel)
-                  (dg->in2 == nullptr || (dg->KH == dg->KW && (dg->KH & 1) && dg->KH * dg->KW < 15 && dg->pad == dg->dil * (dg->KH / 2) && dg->ld_in2 % 8 == 0 &&
-                                          (((dg->IC2 > 0 ? dg->IC2 : dg->IC) * 2) % ROWB) == 0 && dg->ld_in2 >= (dg->IC2 > 0 ? dg->IC2 : dg->IC)));
-  if (!ok) return 0;
+  const bool cand = pair_ok && dg->dtype == WSEG_BF16 && wg->dtype == WSEG_BF16 && dg->mode == 1 && dg->stride == 1 && dg->bm_hint == 0 &&
+                    dg->out != nullptr && dg->out2 == nullptr && dg->epi >= 0 && dg->epi <= 2;
+  if (!cand) return 0;
+  if (conv_validate(dg)) return 0;                 // (the fall-back launch reports the error)
+  {
+    // the two-source form errors out of conv_fill_args when it does not qualify: test its conditions first, quietly
+    const int ic2 = dg->in2 ? (dg->IC2 > 0 ? dg->IC2 : dg->IC) : 0;
+    if (dg->in2 && !(dg->KH == dg->KW && (dg->KH & 1) && dg->KH * dg->KW < 15 && dg->pad == dg->dil * (dg->KH / 2) && dg->OC % 256 == 0 &&
+                     dg->ld_in2 % 8 == 0 && ((ic2 * 2) % ROWB) == 0 && dg->ld_in2 >= ic2))
+      return 0;
+  }
+  if (conv_fill_args(dg, a)) return 0;
+  if (!conv_plan_256(dg, a, ni7) || a.nwg < 0 || a.perm) return 0;
   if (int rc = wseg_wg::wgrad_plan(wg, pl)) return rc;
-  return (pl.kind == 0 && pl.a.stagger == 2) ? 1 : 0;
+  return pl.kind == 0 ? 1 : 0;
 }
 extern "C" int wseg_conv_bwd_pair_fuses(const wseg_conv_desc* dg, const wseg_wgrad_desc* wg) {
-  wseg_wg::Plan pl;
-  return conv_bwd_pair_plan(dg, wg, pl);
+  wseg_wg::Plan pl; Args a; bool ni7;
+  return conv_bwd_pair_plan(dg, wg, a, ni7, pl);
 }
 
 extern "C" int wseg_conv_bwd_pair(const wseg_conv_desc* dg, const wseg_wgrad_desc* wg, void* stream) {
-  wseg_wg::Plan pl;
-  const int fuse = conv_bwd_pair_plan(dg, wg, pl);
+  wseg_wg::Plan pl; Args a; bool ni7 = false;
+  const int fuse = conv_bwd_pair_plan(dg, wg, a, ni7, pl);
   if (fuse < 0) return fuse;
-  const bool ok = fuse == 1;
-  const long M = (long)dg->N * dg->OH * dg->OW + (long)dg->N * dg->OH2 * dg->OW2;
-  if (!ok) {
+  if (fuse != 1) {
     if (int rc = wseg_conv_igemm(dg, stream)) return rc;
     return wseg_conv_wgrad(wg, stream);
   }
-  if (int rc = conv_validate(dg)) return rc;
-  WSEG_CHECK(dg->IH <= 16384 && dg->IW <= 16384 && dg->OH <= 16384 && dg->OW <= 16384 && dg->pad <= 4096 &&
-             (long)dg->N * dg->IH * dg->IW + (long)dg->N * dg->IH2 * dg->IW2 < (1L << 31), "conv_bwd_pair: shape too large for the 256-tile kernel");
-  Args a;
-  a.d = *dg;
-  a.perm = 0; a.Q1 = a.Q2 = 0;
-  static const int early_b = getenv("WSEG_CONV_EARLYB") ? atoi(getenv("WSEG_CONV_EARLYB")) : 1;
-  a.early_b = early_b;
-  a.M = (int)M;
-  const int ic2 = dg->in2 ? (dg->IC2 > 0 ? dg->IC2 : dg->IC) : 0;       // two sources: the second one is an extra last "tap" (as in wseg_conv_igemm)
-  a.taps = dg->KH * dg->KW + (dg->in2 ? 1 : 0);
-  a.cpt = dg->IC * 2 / ROWB;
-  a.cpt2 = ic2 * 2 / ROWB;
-  a.krow = dg->KH * dg->KW * dg->IC + ic2;
-  a.ntn = (dg->OC + 255) / 256;
-  a.row0 = 0;
-  const bool ni7 = conv_rounds_prefer_224(M, a.ntn);
-  const int bmt = ni7 ? 224 : 256;
-  a.nwg = (int)(((M + bmt - 1) / bmt) * a.ntn);
   const int nd_pad = (a.nwg + 7) & ~7;
   const dim3 grid((unsigned)(nd_pad + pl.a.nwg));
   hipStream_t s = (hipStream_t)stream;

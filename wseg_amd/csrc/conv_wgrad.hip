@@ -8,17 +8,12 @@ extern "C" int wseg_conv_wgrad(const wseg_wgrad_desc* d, void* stream) {
   Plan pl;
   if (int rc = wgrad_plan(d, pl)) return rc;
   const Args& a = pl.a;
-  const int stagger = a.stagger;
   const bool unit = pl.unit;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(a.nwg);
   if (pl.kind == 0) {
-    if (stagger == 3 && unit) hipLaunchKernelGGL((conv_wgrad_pipe_kernel<3, 1>), grid, dim3(512), 0, s, a);
-    else if (stagger == 3) hipLaunchKernelGGL((conv_wgrad_pipe_kernel<3, 0>), grid, dim3(512), 0, s, a);
-    else if (stagger == 1) hipLaunchKernelGGL((conv_wgrad_pipe_kernel<1, 0>), grid, dim3(512), 0, s, a);
-    else if (stagger == 0) hipLaunchKernelGGL((conv_wgrad_pipe_kernel<0, 0>), grid, dim3(512), 0, s, a);
-    else if (unit) hipLaunchKernelGGL((conv_wgrad_pipe_kernel<2, 1>), grid, dim3(512), 0, s, a);
-    else hipLaunchKernelGGL((conv_wgrad_pipe_kernel<2, 0>), grid, dim3(512), 0, s, a);
+    if (unit) hipLaunchKernelGGL((conv_wgrad_pipe_kernel<1>), grid, dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((conv_wgrad_pipe_kernel<0>), grid, dim3(512), 0, s, a);
   }
   else if (pl.kind == 1)
     hipLaunchKernelGGL((conv_wgrad_kernel<WSEG_BF16, 256, 256, 2, 4>), grid, dim3(512), 0, s, a);

@@ -43,8 +43,6 @@ struct Args {
   int nsplit, nwg;
   int simple_adv, q64_1, r64_1, q64_2, r64_2;   // pipe kernel: 64 pixels = q*OW + r per row segment (simple_adv: one image wrap at most)
   int wave_epi;      // pipe kernel: 1 = wave-local atomic epilogue (WSEG_WGRAD_EPI)
-  int stagger;       // 1 = ping-pong schedule of the pipe kernel (WSEG_WGRAD_STAGGER; off: its read slots — 24/8/16/0 transposed
-                     //     reads + pixel addressing — are longer and less even than an MFMA slot, the stagger then costs time)
   int diag;          // 0 = normal; timing diagnostics (WSEG_WGRAD_DIAG): 1 = no epilogue stores, 2 = plain stores, 4 / 5 = X / X and dY from the zero page
 };
 
@@ -325,7 +323,7 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void conv_wgrad_kernel(const Args 
 // and the only DMA wait is a counted s_waitcnt vmcnt(4) in p4.  One raw s_barrier per phase.  The transposed
 // fragment reads go through inline asm (hipcc would put vmcnt(0) in front of ds_read_tr builtins while
 // LDS-DMA is in flight), with an explicit lgkmcnt(0) + sched_barrier before the MFMAs.
-template <int SCHED, int UNIT>   // SCHED 0/1: 4 phases lock-step / ping-pong; 2/3: 2 phases lock-step / ping-pong
+template <int UNIT>
                                  // UNIT 1: stride 1 and IH==OH, IW==OW in both segments (the X source row is m + const)
 __device__ __forceinline__ void conv_wgrad_pipe_tile(const Args& a, char* smem, const int bid) {   // (smem: the workgroup's 128 KiB LDS buffer)
   constexpr int BO = 256, BI = 256, NT = 512;
@@ -356,7 +354,7 @@ __device__ __forceinline__ void conv_wgrad_pipe_tile(const Args& a, char* smem, 
 
   // LDS slot (buffer buf, half-tile which = dY0, dY1, X0, X1).  The 2-phase schedules interleave the two buffers at slot
   // granularity so that the buffer offset fits the ds_read immediate (all transposed reads then need no address VALU).
-  auto slot_off = [](int buf, int which) { return SCHED >= 2 ? (which * 2 + buf) * HALF : buf * TILE + which * HALF; };
+  auto slot_off = [](int buf, int which) { return (which * 2 + buf) * HALF; };
   // staging: thread -> rows r0 = tid>>4 and r0+32 of every half-tile, physical 16-B chunk tid&15.
   // All per-K-tile address work is INCREMENTAL (this loop is VALU-sensitive: 64 MFMAs per wave per K-tile leave
   // ~250 issue slots): dY pointers advance by a constant; the X pixel coordinates (n, oy, ox) advance by 64 rows
@@ -563,15 +561,6 @@ __device__ __forceinline__ void conv_wgrad_pipe_tile(const Args& a, char* smem, 
 
   bf16x4 va[2][2][4], vb0[2][2][2], vb1[2][2][2];   // [ks][h][tile] raw transposed reads
   bf16x8 af[2][4], b0[2][2], b1[2][2];
-#define TR(dst, addr) asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(dst) : "v"(addr))
-#define LOAD_A(HA)                                                                                              \
-  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int h = 0; h < 2; ++h)               \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                              \
-      TR(va[ks][h][i], abase + rowoff[ks][h] + ((((HA) * 4 + i) ^ rsw[ks][h]) << 5));
-#define LOAD_B(HB, VB)                                                                                          \
-  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int h = 0; h < 2; ++h)               \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                              \
-      TR(VB[ks][h][j], bbase + rowoff[ks][h] + ((((wc & 1) * 4 + (HB) * 2 + j) ^ rsw[ks][h]) << 5));
 #define PACK_A()                                                                                                \
   _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int i = 0; i < 4; ++i)               \
     af[ks][i] = __builtin_shufflevector(va[ks][0][i], va[ks][1][i], 0, 1, 2, 3, 4, 5, 6, 7);
@@ -589,13 +578,11 @@ __device__ __forceinline__ void conv_wgrad_pipe_tile(const Args& a, char* smem, 
     __builtin_amdgcn_s_setprio(0);                                                                              \
   } while (0)
 
-  if constexpr (SCHED >= 2) {
+  {
     // TWO phases of 32 MFMAs per K-tile (rows 0-63, then 64-127 of the wave tile; both B fragments are read in phase 1 and
-    // kept), each a read slot + an MFMA slot.  stagger == 3: waves 4-7 (the second wave of every SIMD) run one slot behind
-    // waves 0-3, so one wave of a SIMD does its 32 / 16 transposed reads, LDS-DMA issue and pixel addressing while the
-    // other feeds the matrix pipe for 512 cycles.  Refills: dY0/dY1(u+1) in R1, X0/X1(u+2) + the counted wait in R2 — a
+    // kept), each a read slot + an MFMA slot, LOCK-STEP (the ping-pong form of the conv kernel — waves 4-7 one slot
+    // behind — and the 4-phase forms measured slower here: 15.9 / 14.85 / 17.1 vs 14.06 ms per step, profiles/HISTORY.md).  Refills: dY0/dY1(u+1) in R1, X0/X1(u+2) + the counted wait in R2 — a
     // slot's last reader (the late group's read slot) is always one barrier before the early group's next issue into it.
-    constexpr bool stg = SCHED == 3;
     // transposed-read addresses = persistent lane term + immediate: the lane's row (fk*8+q) and 8-B column (p) plus the
     // swizzled 32-B block (t ^ s) — s = q | (fk&1)<<2 does not depend on (ks, h) — and the slot of its wave; the buffer
     // (b*HALF) and the (ks, h) row offsets (ks*32 + h*4 rows) are compile-time immediates.  12 registers, no VALU per read.
@@ -625,7 +612,6 @@ __device__ __forceinline__ void conv_wgrad_pipe_tile(const Args& a, char* smem, 
         tr_read<BO + 8192>(vb1[1][0][j], LTB[2 + j]); tr_read<BO + 9216>(vb1[1][1][j], LTB[2 + j]);
       }
       if (u + 1 < nt) { issue_y(0, b ^ 1); issue_y(1, b ^ 1); }
-      if (stg) asm volatile("s_barrier" ::: "memory");
       WAIT_LDS();
       PACK_A() PACK_B(b0, vb0) PACK_B(b1, vb1)
       MFMA_Q(0, 0, b0);
@@ -639,67 +625,19 @@ __device__ __forceinline__ void conv_wgrad_pipe_tile(const Args& a, char* smem, 
       }
       if (u + 2 < nt) { x_prepare(); issue_x(0, b); issue_x(1, b); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (stg) asm volatile("s_barrier" ::: "memory");
       WAIT_LDS();
       PACK_A()
       MFMA_Q(1, 1, b1);
       MFMA_Q(1, 0, b0);
       asm volatile("s_barrier" ::: "memory");
     };
-    if (stg && wr == 1) asm volatile("s_barrier" ::: "memory");
     int u = 0;
     for (; u + 1 < nt; u += 2) {
       ktile(std::integral_constant<int, 0>{}, u);
       ktile(std::integral_constant<int, 1>{}, u + 1);
     }
     if (u < nt) ktile(std::integral_constant<int, 0>{}, u);
-    if (stg && wr == 0) asm volatile("s_barrier" ::: "memory");
-  } else {
-  // Ping-pong schedule (see conv_igemm256_kernel): waves 4-7 (wr = 1, the second wave of every SIMD) run one slot
-  // behind waves 0-3; every phase = a read slot (transposed fragment reads + LDS-DMA issue + address work) and an MFMA
-  // slot, one barrier after each, so one wave of a SIMD reads while the other feeds the matrix pipe.
-  constexpr bool stg1 = SCHED == 1;
-  if (stg1 && wr == 1) asm volatile("s_barrier" ::: "memory");
-  for (int u = 0; u < nt; ++u) {
-    const int b = u & 1;
-    const unsigned abase = lds0 + b * TILE + wr * HALF;
-    const unsigned bbase = lds0 + b * TILE + (2 + (wc >> 1)) * HALF;
-    // ---- p1: quadrant (0,0)
-    LOAD_A(0) LOAD_B(0, vb0)
-    if (u + 1 < nt) issue_y(0, b ^ 1);
-    if (stg1) asm volatile("s_barrier" ::: "memory");
-    WAIT_LDS();
-    PACK_A() PACK_B(b0, vb0)
-    MFMA_Q(0, 0, b0);
-    asm volatile("s_barrier" ::: "memory");
-    // ---- p2: quadrant (0,1)
-    LOAD_B(1, vb1)
-    if (u + 1 < nt) issue_y(1, b ^ 1);
-    if (stg1) asm volatile("s_barrier" ::: "memory");
-    WAIT_LDS();
-    PACK_B(b1, vb1)
-    MFMA_Q(0, 1, b1);
-    asm volatile("s_barrier" ::: "memory");
-    // ---- p3: quadrant (1,1)
-    LOAD_A(1)
-    if (u + 2 < nt) { x_prepare(); issue_x(0, b); }
-    if (stg1) asm volatile("s_barrier" ::: "memory");
-    WAIT_LDS();
-    PACK_A()
-    MFMA_Q(1, 1, b1);
-    asm volatile("s_barrier" ::: "memory");
-    // ---- p4: quadrant (1,0); counted wait: only X0/X1(u+2) may stay in flight
-    if (u + 2 < nt) { issue_x(1, b); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (stg1) asm volatile("s_barrier" ::: "memory");
-    MFMA_Q(1, 0, b0);
-    asm volatile("s_barrier" ::: "memory");
   }
-  if (stg1 && wr == 0) asm volatile("s_barrier" ::: "memory");
-  }
-#undef TR
-#undef LOAD_A
-#undef LOAD_B
 #undef PACK_A
 #undef PACK_B
 #undef WAIT_LDS
@@ -763,10 +701,10 @@ __device__ __forceinline__ void conv_wgrad_pipe_tile(const Args& a, char* smem, 
   }
 }
 
-template <int SCHED, int UNIT>
+template <int UNIT>
 __global__ __launch_bounds__(512, 2) void conv_wgrad_pipe_kernel(const Args a) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 4 * 16384];
-  conv_wgrad_pipe_tile<SCHED, UNIT>(a, smem, blockIdx.x);
+  conv_wgrad_pipe_tile<UNIT>(a, smem, blockIdx.x);
 }
 
 // host side: validation, tile geometry, split-K choice.  kind: 0 = 256x256 phase-pipelined kernel (bf16, big layers; `unit` picks its UNIT variant),
@@ -829,8 +767,6 @@ static int wgrad_plan(const wseg_wgrad_desc* d, Plan& pl) {
 #endif
   static const int wave_epi = getenv("WSEG_WGRAD_EPI") ? atoi(getenv("WSEG_WGRAD_EPI")) : 1;   // (same-box A/B: 12.64 vs 12.73 ms/step)
   a.wave_epi = wave_epi;
-  static const int stagger = getenv("WSEG_WGRAD_STAGGER") ? atoi(getenv("WSEG_WGRAD_STAGGER")) : 2;   // (2 measured best: 14.06 vs 14.85 / 15.9 ms/step) 0/1: 4 phases lock-step / ping-pong (1 measured slower: 17.1 vs 14.8 ms/step); 2/3: 2 phases lock-step / ping-pong
-  a.stagger = stagger;
   static const bool use_pipe = !(getenv("WSEG_WGRAD_PIPE") && getenv("WSEG_WGRAD_PIPE")[0] == '0');
   static const int unit_ok = getenv("WSEG_WGRAD_UNIT") ? atoi(getenv("WSEG_WGRAD_UNIT")) : 1;
   pl.unit = unit_ok && a.simple_adv && d->stride == 1 && d->IH == d->OH && d->IW == d->OW &&

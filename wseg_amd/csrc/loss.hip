@@ -693,21 +693,42 @@ __global__ __launch_bounds__(1024) void intra_weights_global_kernel(const float*
   __shared__ int present[21], cnt_s, nclass_s;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int c = blockIdx.x;
-  const int PG = P * ranks;
-  auto label = [&](int g) { const int r = g / P; return __float_as_int(rec[(size_t)r * rank_stride + (g - r * P)]); };
-  auto key = [&](int g, int which) {              // which: 1 = similarity, 2 = random key
-    const int r = g / P;
-    return ((unsigned long long)f2key(rec[(size_t)r * rank_stride + (size_t)which * P + (g - r * P)]) << 24) | (unsigned long long)g;
+  // Sweep over the records of ranks [r0, r1): every lane takes FOUR consecutive pixels per step as 16-byte loads of the label / similarity / key
+  // rows (all three requested before any is used; no per-record division), fn(g, label, similarity bits, key bits) per record.  vec: rows 16-byte aligned.
+  const bool vec = (P & 3) == 0 && (rank_stride & 3) == 0 && (reinterpret_cast<size_t>(rec) & 15) == 0;
+  auto sweep = [&](int r0, int r1, bool need_keys, auto&& fn) {
+    for (int r = r0; r < r1; ++r) {
+      const float* base = rec + (size_t)r * rank_stride;
+      for (int p0 = tid * 4; p0 < P; p0 += 4096) {
+        float lb[4], sv[4] = {0.f, 0.f, 0.f, 0.f}, kv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (vec) {
+          const f32x4 l4 = *reinterpret_cast<const f32x4*>(base + p0);
+          f32x4 s4 = (f32x4){0.f, 0.f, 0.f, 0.f}, k4 = s4;
+          if (need_keys) { s4 = *reinterpret_cast<const f32x4*>(base + P + p0); k4 = *reinterpret_cast<const f32x4*>(base + 2 * (size_t)P + p0); }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { lb[e] = l4[e]; sv[e] = s4[e]; kv[e] = k4[e]; }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int p = min(p0 + e, P - 1);
+            lb[e] = base[p];
+            if (need_keys) { sv[e] = base[P + p]; kv[e] = base[2 * (size_t)P + p]; }
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (p0 + e < P) fn(r * P + p0 + e, __float_as_int(lb[e]), f2key(sv[e]), f2key(kv[e]));
+      }
+    }
   };
   if (tid < 21) present[tid] = 0;
   if (tid == 0) cnt_s = 0;
   __syncthreads();
   int mine = 0;
-  for (int g = tid; g < PG; g += 1024) {
-    const int l = label(g);
+  sweep(0, ranks, false, [&](int, int l, unsigned, unsigned) {
     present[l] = 1;                                          // (plain store: every writer writes the same value)
     mine += l == c ? 1 : 0;
-  }
+  });
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
   if (lane == 0 && mine) atomicAdd(&cnt_s, mine);
@@ -716,7 +737,7 @@ __global__ __launch_bounds__(1024) void intra_weights_global_kernel(const float*
   const int len = cnt_s, half = len / 2, kk = (int)((double)len * 0.6);
   const int g0 = own_rank * P;
   if (len < 2) {                                             // (uniform) absent or single-pixel class: counted in C, no term (contrast_train.py:312-313)
-    for (int p = tid; p < P; p += 1024) if (label(g0 + p) == c) w[p] = 0.f;
+    sweep(own_rank, own_rank + 1, false, [&](int g, int l, unsigned, unsigned) { if (l == c) w[g - g0] = 0.f; });
     return;
   }
   if (tid < 3) {
@@ -727,14 +748,14 @@ __global__ __launch_bounds__(1024) void intra_weights_global_kernel(const float*
     for (int i = tid; i < 16 * 3 * 256; i += 1024) (&hist[0][0][0])[i] = 0u;
     __syncthreads();
     const unsigned long long pf0 = prefix[0], pf1 = prefix[1], pf2 = prefix[2];
-    for (int g = tid; g < PG; g += 1024) {
-      if (label(g) != c) continue;
-      const unsigned long long ks = key(g, 1), kr = key(g, 2);
+    sweep(0, ranks, true, [&](int g, int l, unsigned sk, unsigned rk) {
+      if (l != c) return;
+      const unsigned long long ks = ((unsigned long long)sk << 24) | (unsigned long long)g, kr = ((unsigned long long)rk << 24) | (unsigned long long)g;
       const unsigned bs = (unsigned)(ks >> shift) & 255u, br = (unsigned)(kr >> shift) & 255u;
       if (shift == 48 || (ks >> (shift + 8)) == (pf0 >> (shift + 8))) atomicAdd(&hist[wv][0][bs], 1u);
       if (shift == 48 || (ks >> (shift + 8)) == (pf1 >> (shift + 8))) atomicAdd(&hist[wv][1][bs], 1u);
       if (shift == 48 || (kr >> (shift + 8)) == (pf2 >> (shift + 8))) atomicAdd(&hist[wv][2][br], 1u);
-    }
+    });
     __syncthreads();
     if (wv < 3) {                                  // one wave per selection: lane l owns buckets 4l..4l+3 (summed over the 16 private copies)
       const int s_ = wv;
@@ -760,13 +781,13 @@ __global__ __launch_bounds__(1024) void intra_weights_global_kernel(const float*
     __syncthreads();
   }
   const float unit = scale / (2.f * (float)half * (float)nclass_s);
-  for (int p = tid; p < P; p += 1024) {
-    const int g = g0 + p;
-    if (label(g) != c) continue;
-    const unsigned long long ks = key(g, 1), kr = key(g, 2);
-    const int n_sel = (ks >= prefix[0] && ks < prefix[1] ? 1 : 0) + (kr < prefix[2] ? 1 : 0);
-    w[p] = unit * (float)n_sel;
-  }
+  const unsigned long long t0 = prefix[0], t1 = prefix[1], t2 = prefix[2];
+  sweep(own_rank, own_rank + 1, true, [&](int g, int l, unsigned sk, unsigned rk) {
+    if (l != c) return;
+    const unsigned long long ks = ((unsigned long long)sk << 24) | (unsigned long long)g, kr = ((unsigned long long)rk << 24) | (unsigned long long)g;
+    const int n_sel = (ks >= t0 && ks < t1 ? 1 : 0) + (kr < t2 ? 1 : 0);
+    w[g - g0] = unit * (float)n_sel;
+  });
 }
 
 // ---- per-pixel NCE losses + gradient w.r.t. the un-normalised features F (contrast_train.py:261-334).

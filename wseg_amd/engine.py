@@ -18,7 +18,7 @@ import torch
 from . import arch
 from . import _lib as L
 
-HEAD_LD = int(os.environ.get("WSEG_HEAD_LD", "192"))   # fused head rows: [f_proj 128 | cam 21 | zero pad]  (256: the head GEMMs take the 256-tile kernels)
+HEAD_LD = 192          # fused head rows: [f_proj 128 | cam 21 | zero pad 43]  (a 256-wide row for the 256-tile kernels measured slower: profiles/HISTORY.md)
 FUSE_SKIP = os.environ.get("WSEG_FUSE_SKIP", "1") != "0"   # bottleneck skip conv + last conv as one two-source launch (bf16)
 FEAT_LD = 256          # PCM feature rows: [f8_3 64 | f8_4 128 | x_s 3 | zero pad 61]
 
