@@ -83,6 +83,9 @@ typedef struct wseg_conv_desc {
    * convolution (pad = dil*(KH/2)), bf16, OC % 256 == 0, IC2 % 64 == 0 (0: IC2 = IC), in2 on the OUTPUT pixel grid; NULL: none. */
   const void* in2;
   int32_t ld_in2, IC2;
+  int32_t w_rows;      /* rows the weight pack really holds (>= OC; 0 = OC).  A pack zero-padded to a multiple of 256 rows lets a launch whose OC is
+                          not one (the fused head: 149 of 192 columns, resnet38_contrast.py:34-38) run on the 256-tile kernel: it reads whole 256-row
+                          weight tiles and masks the columns >= OC in its epilogue */
 } wseg_conv_desc;
 int wseg_conv_igemm(const wseg_conv_desc* d, void* stream);
 
@@ -101,6 +104,9 @@ typedef struct wseg_wgrad_desc {
   int32_t IC_dw, OC_dw;        /* real extents of dw ([OC_dw][KH*KW][IC_dw]); IC/OC may be padded */
   int32_t tile_hint;           /* 0 = library chooses (256x256 tiles for bf16 with OC,IC >= 256), 128 = force 128x128 */
   int32_t IH2, IW2, OH2, OW2;  /* optional second row segment, as in wseg_conv_desc (OH2 == 0: none) */
+  int32_t dw_rot;              /* column rotation of dw: input channel ic accumulates into column (ic + dw_rot) % IC_dw — the PCM feature rows are
+                                  [f8_3 | f8_4 | x_s] where f9.weight's columns are [x_s | f8_3 | f8_4] (resnet38_contrast.py:53: torch.cat([x_s, f8_3, f8_4])):
+                                  dw_rot = 3 writes f9's gradient in the parameter's own column order (128-tile kernel only; 0 = none) */
 } wseg_wgrad_desc;
 int wseg_conv_wgrad(const wseg_wgrad_desc* d, void* stream);
 /* A layer's data gradient (`dg`: mode 1) and a weight gradient (`wg`) as ONE launch: both depend only on dY (autograd runs them back to back:
@@ -112,9 +118,16 @@ int wseg_conv_bwd_pair_fuses(const wseg_conv_desc* dg, const wseg_wgrad_desc* wg
 
 /* ---- weight packing ----------------------------------------------------------------------
  * master f32 [OC][T][IC] -> fwd pack [OCp][T][ICp] and transposed pack [ICp][T][OCp] in `dtype`
- * (zero padded).  Either destination may be NULL. */
+ * (zero padded).  Either destination may be NULL.  ic_rot: packed input channel ic is the master's column (ic + ic_rot) % IC
+ * (f9.weight's columns [x_s | f8_3 | f8_4] against the feature rows [f8_3 | f8_4 | x_s]: ic_rot = 3, resnet38_contrast.py:53); 0 = none. */
 int wseg_pack_weights(const float* master, void* fwd, void* tr, int OC, int T, int IC,
-                      int OCp, int ICp, int dtype, void* stream);
+                      int OCp, int ICp, int ic_rot, int dtype, void* stream);
+/* the K-concatenated packs of the two-source launches ([W_a[r] | W_b[r]] rows, see wseg_conv_desc.in2) from the per-layer packs, every piece of a
+ * step in ONE launch: piece p copies `rows` x `cols16` 16-byte chunks from src + src_off (row stride ld_src) to dst + dst_off (row stride ld_dst), all in
+ * 16-byte units; `table` (device, int64) holds per piece {first chunk in the launch, src_off, dst_off, rows, cols16, ld_src, ld_dst}.
+ * Replaces torch.cat of the packs (the reference has no counterpart: it runs the skip conv and the last conv of a block as two convolutions,
+ * network/resnet38d.py:35-47, 83-97). */
+int wseg_copy2d_batch(const void* src, void* dst, const long* table, int npieces, long total_chunks, void* stream);
 /* every transposed pack of a training step in ONE launch: layer l is the f32 master [OC][T][IC] at master + off_in[l],
  * written as [IC][T][OC] in `dtype` at out + off_out[l] (element offsets).  `table` (device, int64) holds per layer
  * {index of its first 32x32 tile, off_in, off_out, OC, T, IC}; total_tiles = sum of ceil(OC/32)*ceil(IC/32)*T. */
@@ -182,8 +195,10 @@ int wseg_split_bf16(const float* in, void* hi, void* lo, long total, void* strea
 /* bf16-MFMA variants for the bf16 throughput mode (Fb/Gb/DNb = bf16 copies made with wseg_to_bf16) */
 int wseg_to_bf16(const float* in, void* out, long total, void* stream);
 int wseg_pcm_forward_bf16(const void* Fb, const void* Gb, float* cam_rv, float* den, int N, int hw, void* stream);
-int wseg_pcm_backward_bf16(const void* Fb, const void* Gb, const float* d_cam_rv, const float* cam_rv, const float* den,
-                           float* DN, void* DNb, float* dFh, int N, int hw, void* stream);
+/* backward: Gl / DNl = the LOW parts of the split G = Gb + Gl and DN = DNb + DNl (wseg_split_bf16; DNb and DNl are written here).  The gate-channel
+ * product of the backward pass is a difference of two nearly cancelling sums and runs in split precision (3 bf16 MFMAs), everything else in bf16. */
+int wseg_pcm_backward_bf16(const void* Fb, const void* Gb, const void* Gl, const float* d_cam_rv, const float* cam_rv, const float* den,
+                           float* DN, void* DNb, void* DNl, float* dFh, int N, int hw, void* stream);
 
 /* ---- loss step, contrast_train.py:138-395 (forward values + hand-written gradients) -----------
  * All maps planar f32 [N][21][npix]; label20 = float [N][20] multi-hot; loss outputs are device
@@ -229,6 +244,9 @@ int wseg_rvmin_values(const float* U, const float* label20, float* q, unsigned c
 size_t wseg_select_workspace_bytes(int rows);
 int wseg_select_kth(const float* vals, int rows, int n, int k, int largest, int use_abs, int relu_vals, float* res, void* workspace, void* stream);
 int wseg_select_finish(const float* res, int rows, int k, int relu_vals, float scale, float* loss_out, void* stream);
+/* the 8 logged scalars (contrast_train.py:174, 389-395, 401-408) from the step's accumulators acc = [cls1+cls2, (rvmin1+rvmin2)/2, er_sum, ecr, cross,
+ * cross2, intra, -]:  out8 = [loss, loss_cls, loss_er, loss_ecr, loss_nce, loss_intra_nce, loss_cross_nce, loss_cross_nce2] */
+int wseg_loss_finish(const float* acc, float er_coef, float* out8, void* stream);
 int wseg_rvmin_backward(const float* q, const unsigned char* argc, const float* res, const float* label20, float* dU, int N, int npix, int k, float coef, void* stream);
 int wseg_norm_resize_forward(const float* U, const float* stats, const float* label20, float* out, int N, int S, int OS, void* stream);
 int wseg_norm_resize_backward(const float* G, const float* U, const float* stats, const float* label20, float* dU, int N, int S, int OS, void* stream);

@@ -184,7 +184,9 @@ def test_pcm_bf16_kernels_track_the_exact_f32_kernels():
     rv16 = torch.empty_like(rv32); den16 = torch.empty_like(den32)
     L.pcm_forward_bf16(Fb, Gb, rv16, den16, N, hw)
     DNb = torch.empty(N * hw, 32, device=dev, dtype=torch.bfloat16); d16 = torch.zeros(N * hw, 192, device=dev)
-    L.pcm_backward_bf16(Fb, Gb, d_rv, rv16, den16, DN, DNb, d16, N, hw)
+    Gl = torch.empty_like(Gb); DNl = torch.empty_like(DNb)
+    L.split_bf16(G, Gb, Gl)
+    L.pcm_backward_bf16(Fb, Gb, Gl, d_rv, rv16, den16, DN, DNb, DNl, d16, N, hw)
     assert _rel(rv16.cpu(), rv32.cpu()) < 2e-2
     assert _rel(den16.cpu(), den32.cpu()) < 2e-2
     err = float((d16 - d32).norm() / d32.norm())

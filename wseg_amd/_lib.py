@@ -44,7 +44,7 @@ class ConvDesc(C.Structure):
                 ("mode", C.c_int32), ("epi", C.c_int32), ("dtype", C.c_int32), ("relu_out2", C.c_int32),
                 ("relu_lt", C.c_int32), ("bm_hint", C.c_int32),
                 ("IH2", C.c_int32), ("IW2", C.c_int32), ("OH2", C.c_int32), ("OW2", C.c_int32),
-                ("in2", C.c_void_p), ("ld_in2", C.c_int32), ("IC2", C.c_int32)]
+                ("in2", C.c_void_p), ("ld_in2", C.c_int32), ("IC2", C.c_int32), ("w_rows", C.c_int32)]
 
 
 class WgradDesc(C.Structure):
@@ -54,7 +54,7 @@ class WgradDesc(C.Structure):
                 ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("dil", C.c_int32), ("pad", C.c_int32),
                 ("dtype", C.c_int32), ("split_k", C.c_int32), ("IC_dw", C.c_int32), ("OC_dw", C.c_int32),
                 ("tile_hint", C.c_int32),
-                ("IH2", C.c_int32), ("IW2", C.c_int32), ("OH2", C.c_int32), ("OW2", C.c_int32)]
+                ("IH2", C.c_int32), ("IW2", C.c_int32), ("OH2", C.c_int32), ("OW2", C.c_int32), ("dw_rot", C.c_int32)]
 
 
 def _load():
@@ -103,8 +103,8 @@ TRACK_PAIRS, LAST_PAIR_FUSED = False, None        # tests: whether the last pair
 def conv_igemm(inp, w, out=None, out2=None, *, N, IH, IW, IC, OH, OW, OC, KH, KW, stride=1, dil=1, pad=0,
                mode=0, epi=0, r_pre=None, r_post=None, mask=None, scale=None, shift=None, drop=None,
                ld_in=None, ld_out=None, ld_out2=None, ld_rpre=None, ld_rpost=None, ld_mask=None, relu_out2=1,
-               relu_lt=0, bm_hint=0, seg2=None, in2=None, ld_in2=None, IC2=0, dtype=None, pair_wgrad=None):
-    """pair_wgrad: (x, dy, dw, kwargs of conv_wgrad) — a weight gradient launched in the SAME grid as this data gradient (wseg_conv_bwd_pair; the
+               relu_lt=0, bm_hint=0, seg2=None, in2=None, ld_in2=None, IC2=0, dtype=None, pair_wgrad=None, w_rows=0):
+    """w_rows: rows of the weight pack when it is zero-padded beyond OC (wseg_conv_desc.w_rows).  pair_wgrad: (x, dy, dw, kwargs of conv_wgrad) — a weight gradient launched in the SAME grid as this data gradient (wseg_conv_bwd_pair; the
     library falls back to two launches when the pair does not qualify)."""
     d = ConvDesc()
     d.inp, d.w, d.out, d.out2 = _ptr(inp), _ptr(w), _ptr(out), _ptr(out2)
@@ -120,8 +120,9 @@ def conv_igemm(inp, w, out=None, out2=None, *, N, IH, IW, IC, OH, OW, OC, KH, KW
     if in2 is not None:                          # two sources: w = [OC][KH*KW*IC + IC2]
         d.in2, d.IC2, d.ld_in2 = _ptr(in2), IC2, ld_in2 or (IC2 or IC)
     krow = KH * KW * IC + ((IC2 or IC) if in2 is not None else 0)
-    if w.numel() < OC * krow:                    # (raw pointers beyond this line: a short weight buffer would be read out of bounds)
-        raise RuntimeError(f"conv_igemm: weight buffer has {w.numel()} elements, the launch reads {OC} x {krow}")
+    d.w_rows = w_rows
+    if w.numel() < max(OC, w_rows) * krow:       # (raw pointers beyond this line: a short weight buffer would be read out of bounds)
+        raise RuntimeError(f"conv_igemm: weight buffer has {w.numel()} elements, the launch reads {max(OC, w_rows)} x {krow}")
     sampled, launch_idx = _profile_sample() if PROFILE is not None else (False, 0)
     if sampled:                                  # bench.py: HIP events on the launch stream around this launch
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -148,7 +149,7 @@ def conv_igemm(inp, w, out=None, out2=None, *, N, IH, IW, IC, OH, OW, OC, KH, KW
 
 
 def _wgrad_desc(x, dy, dw, *, N, IH, IW, IC, OH, OW, OC, KH, KW, stride=1, dil=1, pad=0,
-                ld_x=None, ld_dy=None, split_k=0, IC_dw=None, OC_dw=None, tile_hint=0, seg2=None, dtype=None):
+                ld_x=None, ld_dy=None, split_k=0, IC_dw=None, OC_dw=None, tile_hint=0, seg2=None, dtype=None, dw_rot=0):
     d = WgradDesc()
     d.x, d.dy, d.dw = _ptr(x), _ptr(dy), _ptr(dw)
     d.N, d.IH, d.IW, d.IC, d.ld_x = N, IH, IW, IC, ld_x or IC
@@ -156,6 +157,7 @@ def _wgrad_desc(x, dy, dw, *, N, IH, IW, IC, OH, OW, OC, KH, KW, stride=1, dil=1
     d.KH, d.KW, d.stride, d.dil, d.pad = KH, KW, stride, dil, pad
     d.dtype, d.split_k = (dtype_code(x) if dtype is None else dtype), split_k
     d.IC_dw, d.OC_dw, d.tile_hint = IC_dw or IC, OC_dw or OC, tile_hint
+    d.dw_rot = dw_rot
     if seg2 is not None:
         d.IH2, d.IW2, d.OH2, d.OW2 = seg2
     assert dw.dtype == torch.float32
@@ -163,9 +165,9 @@ def _wgrad_desc(x, dy, dw, *, N, IH, IW, IC, OH, OW, OC, KH, KW, stride=1, dil=1
 
 
 def conv_wgrad(x, dy, dw, *, N, IH, IW, IC, OH, OW, OC, KH, KW, stride=1, dil=1, pad=0,
-               ld_x=None, ld_dy=None, split_k=0, IC_dw=None, OC_dw=None, tile_hint=0, seg2=None, dtype=None):
+               ld_x=None, ld_dy=None, split_k=0, IC_dw=None, OC_dw=None, tile_hint=0, seg2=None, dtype=None, dw_rot=0):
     d = _wgrad_desc(x, dy, dw, N=N, IH=IH, IW=IW, IC=IC, OH=OH, OW=OW, OC=OC, KH=KH, KW=KW, stride=stride, dil=dil, pad=pad, ld_x=ld_x, ld_dy=ld_dy,
-                    split_k=split_k, IC_dw=IC_dw, OC_dw=OC_dw, tile_hint=tile_hint, seg2=seg2, dtype=dtype)
+                    split_k=split_k, IC_dw=IC_dw, OC_dw=OC_dw, tile_hint=tile_hint, seg2=seg2, dtype=dtype, dw_rot=dw_rot)
     assert dw.dtype == torch.float32
     if PROFILE_WGRAD is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -177,9 +179,14 @@ def conv_wgrad(x, dy, dw, *, N, IH, IW, IC, OH, OW, OC, KH, KW, stride=1, dil=1,
         PROFILE_WGRAD.append((ev0, ev1, 2.0 * pix * IC * OC * KH * KW, f"wgrad {IC}->{OC} k{KH} s{stride} d{dil} {OH}x{OW}"))
 
 
-def pack_weights(master, fwd, tr, OC, T, IC, OCp, ICp, dtype):
+def pack_weights(master, fwd, tr, OC, T, IC, OCp, ICp, dtype, ic_rot=0):
     check(lib.wseg_pack_weights(C.c_void_p(_ptr(master)), C.c_void_p(_ptr(fwd)), C.c_void_p(_ptr(tr)),
-                                OC, T, IC, OCp, ICp, dtype, C.c_void_p(stream_ptr())), "wseg_pack_weights")
+                                OC, T, IC, OCp, ICp, ic_rot, dtype, C.c_void_p(stream_ptr())), "wseg_pack_weights")
+
+
+def copy2d_batch(src, dst, table, npieces, total_chunks):
+    check(lib.wseg_copy2d_batch(C.c_void_p(_ptr(src)), C.c_void_p(_ptr(dst)), C.c_void_p(_ptr(table)), npieces, C.c_long(total_chunks),
+                                C.c_void_p(stream_ptr())), "wseg_copy2d_batch")
 
 
 def pack_transposed_batch(master, out, table, nlayers, total_tiles, dtype):
@@ -295,6 +302,7 @@ def cls_loss(stats, label20, loss_out, plane_bias, N, npix, coef): _call("wseg_c
 def rvmin_values(U, label20, q, argc, N, npix): _call("wseg_rvmin_values", _v(U), _v(label20), _v(q), _v(argc), N, npix)
 def select_workspace_bytes(rows): return int(lib.wseg_select_workspace_bytes(rows))
 def select_kth(vals, rows, n, k, largest, use_abs, relu_vals, res, ws): _call("wseg_select_kth", _v(vals), rows, n, k, int(largest), int(use_abs), int(relu_vals), _v(res), _v(ws))
+def loss_finish(acc, er_coef, out8): _call("wseg_loss_finish", _v(acc), _f(er_coef), _v(out8))
 def select_finish(res, rows, k, relu_vals, scale, loss_out): _call("wseg_select_finish", _v(res), rows, k, int(relu_vals), _f(scale), _v(loss_out))
 def rvmin_backward(q, argc, res, label20, dU, N, npix, k, coef): _call("wseg_rvmin_backward", _v(q), _v(argc), _v(res), _v(label20), _v(dU), N, npix, k, _f(coef))
 def norm_resize_forward(U, stats, label20, out, N, S, OS): _call("wseg_norm_resize_forward", _v(U), _v(stats), _v(label20), _v(out), N, S, OS)
@@ -355,8 +363,20 @@ def gemm256_probe(A, B, Cout, M, N, K, variant=0):
     check(lib.wseg_gemm256_probe(_v(A), _v(B), _v(Cout), M, N, K, variant, _s()), "wseg_gemm256_probe")
 
 
+def debug_stamps(n_wg):
+    """probe builds: the in-kernel stamps of the last 256-tile conv launch, [n_wg, 24] uint64: 8 wall-clock stamps (100 MHz) + 2 x 8 slot cycle sums in WSEG_PROBES=2 builds (csrc/conv_igemm.hip)"""
+    if not hasattr(lib, "wseg_debug_stamps"):
+        raise RuntimeError("wseg_debug_stamps exists in probe builds only: rebuild with `WSEG_PROBES=1 bash wseg_amd/csrc/build.sh`")
+    import numpy as np
+    torch.cuda.synchronize()
+    buf = np.zeros((min(n_wg, 4096), 24), dtype=np.uint64)
+    lib.wseg_debug_stamps.argtypes = [C.c_void_p, C.c_size_t]
+    check(lib.wseg_debug_stamps(buf.ctypes.data_as(C.c_void_p), C.c_size_t(buf.nbytes)), "wseg_debug_stamps")
+    return buf
+
+
 def to_bf16(inp, out): _call("wseg_to_bf16", _v(inp), _v(out), C.c_long(inp.numel()))
 def split_bf16(inp, hi, lo): _call("wseg_split_bf16", _v(inp), _v(hi), _v(lo), C.c_long(inp.numel()))
 def pack_x3(src, dst): _call("wseg_pack_x3", _v(src), _v(dst), C.c_long(src.numel()))
 def pcm_forward_bf16(Fb, Gb, cam_rv, den, N, hw): _call("wseg_pcm_forward_bf16", _v(Fb), _v(Gb), _v(cam_rv), _v(den), N, hw)
-def pcm_backward_bf16(Fb, Gb, d_cam_rv, cam_rv, den, DN, DNb, dFh, N, hw): _call("wseg_pcm_backward_bf16", _v(Fb), _v(Gb), _v(d_cam_rv), _v(cam_rv), _v(den), _v(DN), _v(DNb), _v(dFh), N, hw)
+def pcm_backward_bf16(Fb, Gb, Gl, d_cam_rv, cam_rv, den, DN, DNb, DNl, dFh, N, hw): _call("wseg_pcm_backward_bf16", _v(Fb), _v(Gb), _v(Gl), _v(d_cam_rv), _v(cam_rv), _v(den), _v(DN), _v(DNb), _v(DNl), _v(dFh), N, hw)

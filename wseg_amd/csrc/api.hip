@@ -20,24 +20,26 @@ namespace {
 
 // ---- weight packing: cast + zero-pad (fwd) and cast + transpose (tr) ----------------------
 template <int DT>
-__global__ void pack_fwd_kernel(const float* __restrict__ w, void* __restrict__ out, int OC, int T, int IC, int OCp, int ICp) {
+__global__ void pack_fwd_kernel(const float* __restrict__ w, void* __restrict__ out, int OC, int T, int IC, int OCp, int ICp, int ic_rot) {
   const size_t total = (size_t)OCp * T * ICp;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int ic = (int)(i % ICp);
     const size_t r = i / ICp;
     const int t = (int)(r % T), oc = (int)(r / T);
-    const float v = (oc < OC && ic < IC) ? w[((size_t)oc * T + t) * IC + ic] : 0.f;
+    const int src = ic + ic_rot >= IC ? ic + ic_rot - IC : ic + ic_rot;        // packed column ic <- master column (ic + ic_rot) % IC
+    const float v = (oc < OC && ic < IC) ? w[((size_t)oc * T + t) * IC + src] : 0.f;
     elem<DT>::st(out, i, v);
   }
 }
 template <int DT>
-__global__ void pack_tr_kernel(const float* __restrict__ w, void* __restrict__ out, int OC, int T, int IC, int OCp, int ICp) {
+__global__ void pack_tr_kernel(const float* __restrict__ w, void* __restrict__ out, int OC, int T, int IC, int OCp, int ICp, int ic_rot) {
   __shared__ float tile[32][33];
   const int t = blockIdx.z;
   const int oc0 = blockIdx.y * 32, ic0 = blockIdx.x * 32;
   for (int r = threadIdx.y; r < 32; r += 8) {
     const int oc = oc0 + r, ic = ic0 + threadIdx.x;
-    tile[r][threadIdx.x] = (oc < OC && ic < IC) ? w[((size_t)oc * T + t) * IC + ic] : 0.f;
+    const int src = ic + ic_rot >= IC ? ic + ic_rot - IC : ic + ic_rot;
+    tile[r][threadIdx.x] = (oc < OC && ic < IC) ? w[((size_t)oc * T + t) * IC + src] : 0.f;
   }
   __syncthreads();
   for (int r = threadIdx.y; r < 32; r += 8) {
@@ -198,20 +200,20 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
 }  // namespace
 
 extern "C" int wseg_pack_weights(const float* master, void* fwd, void* tr, int OC, int T, int IC,
-                                 int OCp, int ICp, int dtype, void* stream) {
+                                 int OCp, int ICp, int ic_rot, int dtype, void* stream) {
   WSEG_CHECK(master && (fwd || tr), "pack_weights: null pointer");
-  WSEG_CHECK(OCp >= OC && ICp >= IC && T >= 1, "pack_weights: bad padded shape");
+  WSEG_CHECK(OCp >= OC && ICp >= IC && T >= 1 && ic_rot >= 0 && ic_rot < IC, "pack_weights: bad padded shape / rotation");
   hipStream_t s = (hipStream_t)stream;
   if (fwd) {
     const size_t total = (size_t)OCp * T * ICp;
     const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
-    if (dtype == WSEG_BF16) hipLaunchKernelGGL(pack_fwd_kernel<WSEG_BF16>, dim3(blocks), dim3(256), 0, s, master, fwd, OC, T, IC, OCp, ICp);
-    else hipLaunchKernelGGL(pack_fwd_kernel<WSEG_F32>, dim3(blocks), dim3(256), 0, s, master, fwd, OC, T, IC, OCp, ICp);
+    if (dtype == WSEG_BF16) hipLaunchKernelGGL(pack_fwd_kernel<WSEG_BF16>, dim3(blocks), dim3(256), 0, s, master, fwd, OC, T, IC, OCp, ICp, ic_rot);
+    else hipLaunchKernelGGL(pack_fwd_kernel<WSEG_F32>, dim3(blocks), dim3(256), 0, s, master, fwd, OC, T, IC, OCp, ICp, ic_rot);
   }
   if (tr) {
     dim3 grid((ICp + 31) / 32, (OCp + 31) / 32, T);
-    if (dtype == WSEG_BF16) hipLaunchKernelGGL(pack_tr_kernel<WSEG_BF16>, grid, dim3(32, 8), 0, s, master, tr, OC, T, IC, OCp, ICp);
-    else hipLaunchKernelGGL(pack_tr_kernel<WSEG_F32>, grid, dim3(32, 8), 0, s, master, tr, OC, T, IC, OCp, ICp);
+    if (dtype == WSEG_BF16) hipLaunchKernelGGL(pack_tr_kernel<WSEG_BF16>, grid, dim3(32, 8), 0, s, master, tr, OC, T, IC, OCp, ICp, ic_rot);
+    else hipLaunchKernelGGL(pack_tr_kernel<WSEG_F32>, grid, dim3(32, 8), 0, s, master, tr, OC, T, IC, OCp, ICp, ic_rot);
   }
   WSEG_LAUNCH_CHECK();
   return 0;
@@ -262,6 +264,28 @@ extern "C" int wseg_dropout_scale(const float* u, float* out, long total, long s
 extern "C" int wseg_pack_transposed_batch_bf16(const void* mirror, void* out, const long* table, int nlayers, long total_tiles, void* stream) {
   WSEG_CHECK(mirror && out && table && nlayers > 0 && total_tiles > 0 && total_tiles < (1L << 31), "pack_transposed_batch_bf16: bad arguments");
   hipLaunchKernelGGL(pack_tr_batch_bf16_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)mirror, (bf16_t*)out, table, nlayers);
+  WSEG_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- K-concatenated weight packs of the two-source conv launches (wseg_conv_desc.in2): rows [W_a[r] | W_b[r]] built from the per-layer packs.
+// ONE launch copies every piece of a step: piece p = `rows` rows of `cols16` 16-byte chunks from src + src_off (row stride ld_src) to dst + dst_off
+// (row stride ld_dst); offsets and strides in 16-byte units; table[p] = {first chunk of the piece in the launch, src_off, dst_off, rows, cols16,
+// ld_src, ld_dst}.  (Round 2 made these packs with six torch.cat calls per step.)
+static __global__ void copy2d_batch_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, const long* __restrict__ table, int npieces, long total) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int lo = 0, hi = npieces - 1;                    // last piece whose first chunk <= i
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (table[mid * 7] <= i) lo = mid; else hi = mid - 1; }
+    const long* t = table + lo * 7;
+    const long j = i - t[0];
+    const long row = j / t[4], c = j - row * t[4];
+    dst[t[2] + row * t[6] + c] = src[t[1] + row * t[5] + c];
+  }
+}
+extern "C" int wseg_copy2d_batch(const void* src, void* dst, const long* table, int npieces, long total_chunks, void* stream) {
+  WSEG_CHECK(src && dst && table && npieces > 0 && total_chunks > 0 && ((size_t)src & 15) == 0 && ((size_t)dst & 15) == 0, "copy2d_batch: bad arguments");
+  const unsigned blocks = (unsigned)std::min<long>((total_chunks + 255) / 256, 8192);
+  hipLaunchKernelGGL(copy2d_batch_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)src, (uint4*)dst, table, npieces, total_chunks);
   WSEG_LAUNCH_CHECK();
   return 0;
 }

@@ -7,6 +7,8 @@ FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17"
 # WSEG_PROBES=1: also compile the development probes (gemm256_probe, the 256x128 conv tile, the WSEG_WGRAD_DIAG / zero-page timing
 # diagnostics, which give wrong results by design) — never part of the product library
 if [ "${WSEG_PROBES:-0}" = "1" ]; then FLAGS="$FLAGS -DWSEG_PROBES"; fi
+# WSEG_PROBES=2: the probes plus per-slot cycle sums inside the conv main loop (serialises what the real kernel overlaps: shares only)
+if [ "${WSEG_PROBES:-0}" = "2" ]; then FLAGS="$FLAGS -DWSEG_PROBES -DWSEG_SLOTS"; fi
 SRCS=$(ls *.hip)
 mkdir -p _obj
 pids=()

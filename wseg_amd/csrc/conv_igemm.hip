@@ -23,6 +23,46 @@
 #define WSEG_DIAG_ZERO_B(d) false
 #endif
 
+#ifdef WSEG_PROBES
+// In-kernel stamps of the 256-tile body (probe builds only: `WSEG_PROBES=1 bash build.sh`): per workgroup 8 x s_memrealtime (100 MHz) — entry, gather
+// set-up done, first tiles landed, main loop done (early wave group), tile done; slots 5 / 6: main loop / tile done of the late group (wave 4);
+// slot 7: XCC id.  Written to a buffer of their own that no kernel reads (scripts/conv_tile_breakdown.py fetches it).
+__device__ unsigned long long g_wseg_stamps[24 * 4096];   // per workgroup: 8 wall-clock stamps, then (WSEG_SLOTS builds) 8 slot sums of wave 0 and 8 of wave 4
+#define WSEG_STAMP(slot, wave)                                                                                  \
+  do { if (threadIdx.x == (wave) * 64 && bid < 4096) g_wseg_stamps[bid * 24 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" int wseg_debug_stamps(void* out, size_t bytes) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wseg_stamps), bytes < sizeof(g_wseg_stamps) ? bytes : sizeof(g_wseg_stamps)) == hipSuccess ? 0 : -1;
+}
+#else
+#define WSEG_STAMP(slot, wave) do { } while (0)
+#endif
+// WSEG_SLOTS (with WSEG_PROBES): cycles (s_memtime) a wave spends in each slot of the main loop, summed over the K-tiles: read slot 1 (fragment reads
+// until they have landed + LDS-DMA issue), barrier, MFMA slot 1, barrier, read slot 2 (+ the counted DMA wait), barrier, MFMA slot 2, barrier.
+// The stamps serialise what the real kernel overlaps (each waits for lgkmcnt(0)): read the SHARES, not the run time of this build.
+#if defined(WSEG_PROBES) && defined(WSEG_SLOTS)
+#define WSEG_SLOT_DECL() unsigned long long sl_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tp_ = 0
+#define WSEG_SLOT_BEGIN() asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tp_) :: "memory")
+#define WSEG_SLOT(i)                                                                                            \
+  do {                                                                                                          \
+    unsigned long long t_;                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                          \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");                               \
+    __builtin_amdgcn_sched_barrier(0);                                                                          \
+    sl_[i] += t_ - tp_; tp_ = t_;                                                                               \
+  } while (0)
+#define WSEG_SLOT_FLUSH()                                                                                       \
+  do {                                                                                                          \
+    if ((threadIdx.x == 0 || threadIdx.x == 256) && bid < 4096) {                                               \
+      _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) g_wseg_stamps[bid * 24 + 8 + (threadIdx.x >> 8) * 8 + i_] = sl_[i_]; \
+    }                                                                                                           \
+  } while (0)
+#else
+#define WSEG_SLOT_DECL() do { } while (0)
+#define WSEG_SLOT_BEGIN() do { } while (0)
+#define WSEG_SLOT(i) do { } while (0)
+#define WSEG_SLOT_FLUSH() do { } while (0)
+#endif
+
 namespace {
 
 constexpr int BN = 128, ROWB = 128;                // out-channel rows per tile, bytes of K per LDS row
@@ -580,6 +620,7 @@ __device__ __forceinline__ void conv_igemm256_tile(const Args& a, char* smem, co
   const int m0 = a.row0 + tm * BMT, n0 = tn * 256;
   const int wr = wid >> 2, wc = wid & 3;
   const int frow = lane & 15, fk = lane >> 4, sw = (lane >> 1) & 7;
+  WSEG_STAMP(0, 0);
 
   const char* zero = reinterpret_cast<const char*>(g_wseg_zero_page);
   const char* IN = reinterpret_cast<const char*>(d.in);
@@ -608,7 +649,7 @@ __device__ __forceinline__ void conv_igemm256_tile(const Args& a, char* smem, co
       if (ntaps == 0) { tl = 0ull; ntaps = 1; }    // (a class without taps: one all-padding tap keeps the pipeline uniform)
     }
   }
-  const char* bptr0 = Wp + ((size_t)(n0 + r0) * a.krow + (size_t)lc * CH) * ES;   // OC % 256 == 0 (host-checked)
+  const char* bptr0 = Wp + ((size_t)(n0 + r0) * a.krow + (size_t)lc * CH) * ES;   // the weight pack holds whole 256-row tiles (host-checked: OC % 256 == 0 or w_rows)
   const char* bptr = bptr0 + (size_t)(tl & 15ull) * d.IC * ES;
   int b_ti = 0, b_cc = 0;                          // (perm only) position of the NEXT B tile in the tap list
   const int brs = 64 * a.krow * ES;                // bytes between B rows r0 + 64*j
@@ -691,8 +732,10 @@ __device__ __forceinline__ void conv_igemm256_tile(const Args& a, char* smem, co
   // prologue: tile 0's A halves (B(0), B(1) are already in flight); everything must have landed before the first reads
   set_tap((int)(tl & 15ull));
   issue_a(0, 0); issue_a(1, 0); advance_a();
+  WSEG_STAMP(1, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  WSEG_STAMP(2, 0);
 
   bf16x8 af[2][4], b0[2][2], b1[2][2];             // [ks][tile]: A sub-tile (64 rows), B sub-tiles hb = 0 / 1 (32 cols each)
   auto ldA = [&](const char* aH, int ha) {
@@ -749,32 +792,54 @@ __device__ __forceinline__ void conv_igemm256_tile(const Args& a, char* smem, co
     // SIMD (wave w and w + 4 = the two M halves) run one slot apart — while one feeds the matrix pipe the other does its reads; every wave executes
     // the same number of barriers (waves 4-7 one extra before the loop, waves 0-3 one after).  Measured alternatives (4 phases of 16 MFMAs,
     // lock-step forms): profiles/HISTORY.md.
+    WSEG_SLOT_DECL();
     if (wr == 1) __builtin_amdgcn_s_barrier();
+    WSEG_SLOT_BEGIN();
     for (int u = 0; u < nt; ++u) {
       const int b = u & 1;
       const char* aH = smem + b * TILE256 + wr * HALF256;
       const char* bH = smem + b * TILE256 + (2 + (wc >> 1)) * HALF256;
+      // (read slot 1 holds 16 fragment reads + the 4 LDS-DMA requests of the next A tile, slot 2 8 reads + the 4 requests of B(u+2) + the counted
+      //  wait.  In-kernel slot stamps (profiles/r03_conv_slots.txt) put slot 1 at ~800 cycles against 370 for slot 2 and 570 / 440 for the MFMA slots
+      //  beside them — the matrix pipe waits for slot 1.  Re-balancing was measured in round 3 and gains nothing: rows 0-63 of A in slot 1 and rows
+      //  64-127 in slot 2, the requests in front of the reads or behind an lgkmcnt(0): 1.29-1.37 us per K-tile against 1.31 — the sum of the two
+      //  read slots stays above the sum of the MFMA slots whatever their split; profiles/HISTORY.md.)
       ldA(aH, 0); ldB(bH, 0, b0); ldB(bH, 1, b1);
       if (u + 1 < nt) { issue_a(0, b ^ 1); issue_a(1, b ^ 1); advance_a(); }
+      WSEG_SLOT(0);
       __builtin_amdgcn_s_barrier();
+      WSEG_SLOT(1);
       MFMA_Q(0, 0, b0);
       MFMA_Q(0, 1, b1);
+      WSEG_SLOT(2);
       __builtin_amdgcn_s_barrier();
+      WSEG_SLOT(3);
       ldA(aH, 1);
       if (u + 2 < nt) { issue_b(0, b); issue_b(1, b); advance_b(); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      WSEG_SLOT(4);
       __builtin_amdgcn_s_barrier();
+      WSEG_SLOT(5);
       MFMA_Q(1, 1, b1);
       MFMA_Q(1, 0, b0);
+      WSEG_SLOT(6);
       __builtin_amdgcn_s_barrier();
+      WSEG_SLOT(7);
     }
+    WSEG_SLOT_FLUSH();
     if (wr == 0) __builtin_amdgcn_s_barrier();
   }
 #undef MFMA_Q
 
   // ---- epilogue, wave-local (see wave_local_epilogue)
+  WSEG_STAMP(3, 0); WSEG_STAMP(5, 4);
   __syncthreads();                                 // every wave is done with the pipeline buffers
   wave_local_epilogue<EPI, NI, DT>(a, smem, wid, lane, m0 + wr * RH, wc * 64, n0, acc);
+#ifdef WSEG_PROBES
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (the stamp means: this wave's stores have left)
+  WSEG_STAMP(4, 0); WSEG_STAMP(6, 4);
+  if (threadIdx.x == 0 && bid < 4096) g_wseg_stamps[bid * 24 + 7] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));   // HW_REG_XCC_ID bits 0..3
+#endif
 }
 
 template <int EPI, int NI = 8, int DT = WSEG_BF16>
@@ -968,6 +1033,7 @@ static int conv_validate(const wseg_conv_desc* d) {
   if (d->mask) WSEG_CHECK(d->ld_mask % 8 == 0, "conv_igemm: bad ld_mask");
   const long M = (long)d->N * d->OH * d->OW + (long)d->N * d->OH2 * d->OW2;
   WSEG_CHECK(d->OH2 >= 0 && (d->OH2 == 0 || (d->OW2 > 0 && d->IH2 > 0 && d->IW2 > 0)), "conv_igemm: bad second segment");
+  WSEG_CHECK(d->w_rows == 0 || d->w_rows >= d->OC, "conv_igemm: w_rows=%d < OC=%d", d->w_rows, d->OC);
   WSEG_CHECK(M < (1L << 31) && (long)d->N * d->IH * d->IW * d->ld_in < (1L << 40), "conv_igemm: tensor too large");
   return 0;
 }
@@ -1019,7 +1085,9 @@ static int conv_fill_args(const wseg_conv_desc* d, Args& a) {
 static bool conv_plan_256(const wseg_conv_desc* d, Args& a, bool& ni7) {
   const long M = a.M;
   ni7 = false;
-  if (!((d->dtype == WSEG_BF16 || (d->dtype == WSEG_F32X3 && d->in2 == nullptr)) && d->OC % 256 == 0 && d->bm_hint != 64 && d->bm_hint != 128 &&
+  // (OC % 256 != 0: only with a weight pack zero-padded to whole 256-row tiles, wseg_conv_desc.w_rows — the epilogue masks the columns >= OC)
+  const bool oc_ok = d->OC % 256 == 0 || (d->in2 == nullptr && d->w_rows >= ((d->OC + 255) / 256) * 256);
+  if (!((d->dtype == WSEG_BF16 || (d->dtype == WSEG_F32X3 && d->in2 == nullptr)) && oc_ok && d->bm_hint != 64 && d->bm_hint != 128 &&
         d->bm_hint != 259 && d->bm_hint >= 0))
     return false;
   static const int auto256 = getenv("WSEG_CONV256") ? atoi(getenv("WSEG_CONV256")) : 1;   // (0: A/B switch — 128-tile kernel everywhere)

@@ -308,8 +308,11 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void conv_wgrad_kernel(const Args 
     for (int idx = tid; idx < EPI_ROWS * BI; idx += NT) {
       const int row = idx / BI, col = idx - row * BI;
       const int oc = oc0 + ps * EPI_ROWS + row, ic = ic0 + col;
-      if (oc < d.OC_dw && ic < d.IC_dw)
-        atomicAdd(&d.dw[(size_t)oc * row_stride + (size_t)tap * d.IC_dw + ic], img[row * EPI_LD + col]);
+      if (oc < d.OC_dw && ic < d.IC_dw) {
+        int icw = ic + d.dw_rot;                                     // (column rotation of dw: see wseg_wgrad_desc.dw_rot)
+        icw = icw >= d.IC_dw ? icw - d.IC_dw : icw;
+        atomicAdd(&d.dw[(size_t)oc * row_stride + (size_t)tap * d.IC_dw + icw], img[row * EPI_LD + col]);
+      }
     }
     __syncthreads();
   }
@@ -718,6 +721,7 @@ static int wgrad_plan(const wseg_wgrad_desc* d, Plan& pl) {
              "conv_wgrad: IC/OC/ld must be multiples of 8 (IC=%d OC=%d ld_x=%d ld_dy=%d)", d->IC, d->OC, d->ld_x, d->ld_dy);
   WSEG_CHECK(d->ld_x >= d->IC && d->ld_dy >= d->OC, "conv_wgrad: leading dims too small");
   WSEG_CHECK(d->IC_dw > 0 && d->IC_dw <= d->IC && d->OC_dw > 0 && d->OC_dw <= d->OC, "conv_wgrad: bad dw extents");
+  WSEG_CHECK(d->dw_rot >= 0 && d->dw_rot < d->IC_dw, "conv_wgrad: dw_rot=%d must lie in [0, IC_dw)", d->dw_rot);
   WSEG_CHECK(d->N > 0 && d->OH > 0 && d->OW > 0 && d->IH > 0 && d->IW > 0 && d->stride >= 1 && d->dil >= 1, "conv_wgrad: bad shape");
   const long M = (long)d->N * d->OH * d->OW + (long)d->N * d->OH2 * d->OW2;
   WSEG_CHECK(d->OH2 >= 0 && (d->OH2 == 0 || (d->OW2 > 0 && d->IH2 > 0 && d->IW2 > 0)), "conv_wgrad: bad second segment");
@@ -772,6 +776,7 @@ static int wgrad_plan(const wseg_wgrad_desc* d, Plan& pl) {
   pl.unit = unit_ok && a.simple_adv && d->stride == 1 && d->IH == d->OH && d->IW == d->OW &&
             (d->OH2 == 0 || (d->IH2 == d->OH2 && d->IW2 == d->OW2));
   pl.kind = (big && use_pipe) ? 0 : (big ? 1 : 2);
+  WSEG_CHECK(d->dw_rot == 0 || pl.kind == 2, "conv_wgrad: dw_rot is supported by the 128-tile kernel only");
   return 0;
 }
 }  // namespace

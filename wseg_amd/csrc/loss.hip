@@ -1317,6 +1317,20 @@ extern "C" int wseg_select_finish(const float* res, int rows, int k, int relu_va
   return 0;
 }
 
+// the 8 logged scalars of contrast_train.py:174, 389-395, 401-408 from the step's accumulators (one launch instead of a handful of torch scalar ops):
+// acc = [cls1+cls2, (rvmin1+rvmin2)/2, er_sum, ecr, cross, cross2, intra, -]; out = [loss, cls, er, ecr, nce, intra, cross, cross2]
+static __global__ void loss_finish_kernel(const float* __restrict__ acc, float er_coef, float* __restrict__ out) {
+  if (threadIdx.x != 0) return;
+  const float cls = acc[0] * 0.5f + acc[1], er = acc[2] * er_coef, ecr = acc[3], nce = acc[4] + acc[5] + acc[6];
+  out[0] = cls + er + ecr + nce; out[1] = cls; out[2] = er; out[3] = ecr; out[4] = nce; out[5] = acc[6]; out[6] = acc[4]; out[7] = acc[5];
+}
+extern "C" int wseg_loss_finish(const float* acc, float er_coef, float* out8, void* stream) {
+  WSEG_CHECK(acc && out8, "loss_finish: bad arguments");
+  hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, ST, acc, er_coef, out8);
+  WSEG_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int wseg_rvmin_backward(const float* q, const unsigned char* argc, const float* res, const float* label20, float* dU,
                                    int N, int npix, int k, float coef, void* stream) {
   WSEG_CHECK(q && argc && res && label20 && dU, "rvmin_backward: bad arguments");

@@ -302,20 +302,24 @@ class Engine:
                 if cname not in no_dgrad:
                     P["wt"][cname] = (self.flat_wt3 if dt == L.F32X3 else self.flat_wt)[off:off + n].view(ci, T, co)
         def late():
-            # bottleneck blocks (b6, b7), bf16 mode: skip conv and last conv as ONE two-source product (K-concatenation):
-            # rows [W_branch1[oc] | W_branch2b2[oc]] — the skip output is then neither written nor re-read (444 MB each way for b7)
+            # bf16 mode: a block's skip conv and its last conv as ONE two-source product (K-concatenation): rows [W_a[oc] | W_b[oc]] — the skip output is
+            # then neither written nor re-read (444 MB each way for b7).  b6 / b7: [W_branch1 | W_branch2b2]; b5 (the residual-block form, 3x3 last conv +
+            # 1x1 skip conv at stride 1): [W_branch2b1 (9 taps) | W_branch1].  All pieces are copied from the bf16 mirror in ONE launch into buffers
+            # that persist across steps (`_fused_plan`).
             if dt == L.BF16 and FUSE_SKIP:
-                for b in arch.BLOCKS:                               # (b5: the residual-block form — 3x3 last conv + 1x1 skip conv at stride 1)
-                    if b[1] == "res" and b[0] not in arch.FROZEN_BLOCKS and not arch.block_same_shape(b) and b[5] == 1 and b[4] % 256 == 0 and b[2] % 256 == 0:
-                        nm, cin_, mid_, cout_ = b[0], b[2], b[3], b[4]
-                        P["w"][nm + ".skip_fused"] = torch.cat([P["w"][nm + ".conv_branch2b1"].reshape(cout_, 9 * mid_),
-                                                                 P["w"][nm + ".conv_branch1"].reshape(cout_, cin_)], dim=1)
-                for b in arch.BLOCKS:
-                    if b[1] != "res" and b[0] not in arch.FROZEN_BLOCKS and b[2] == b[4] // 2 and b[5] == 1 and b[4] % 256 == 0:
-                        P["w"][b[0] + ".skip_fused"] = torch.cat([P["w"][b[0] + ".conv_branch1"], P["w"][b[0] + ".conv_branch2b2"]], dim=1)
+                plan = self._fused_plan(device)
+                for nm, buf in plan["fwd_bufs"].items():
+                    P["w"][nm + ".skip_fused"] = buf
+                L.copy2d_batch(mirror, plan["fwd_flat"], plan["fwd_table"], plan["fwd_table"].shape[0], plan["fwd_chunks"])
             # fused head: rows [fc_proj | fc8 | 0]; its transposed pack is made from the two f32 masters directly
-            wh = torch.zeros(HEAD_LD, 1, 4096, device=device, dtype=tdt)
-            wht = torch.zeros(4096, 1, HEAD_LD, device=device, dtype=tdt)
+            hb = getattr(self, "_head_bufs", None)               # persistent: the zero padding (rows / columns 149..191) is written once
+            if hb is None or hb[0] != (dt, str(device)):
+                # (the forward pack holds 256 rows — 107 of them zero: the head GEMM then runs on the 256-tile kernel, which reads whole 256-row weight
+                #  tiles and masks the columns >= HEAD_LD; conv_igemm w_rows)
+                hb = self._head_bufs = ((dt, str(device)), torch.zeros(256, 1, 4096, device=device, dtype=tdt),
+                                        torch.zeros(4096, 1, HEAD_LD, device=device, dtype=tdt),
+                                        torch.empty(192, 1, FEAT_LD, device=device, dtype=tdt), torch.empty(FEAT_LD, 1, 192, device=device, dtype=tdt))
+            wh, wht = hb[1], hb[2]
             pdt = L.F32 if dt == L.F32X3 else dt                  # (split-bf16: f32 packs first, split below)
             L.pack_weights(net.fc_proj.weight.detach(), wh, None, 128, 1, 4096, 128, 4096, pdt)
             L.pack_weights(net.fc8.weight.detach(), wh[128:], None, 21, 1, 4096, 21, 4096, pdt)
@@ -327,12 +331,10 @@ class Engine:
             for nm, (co, ci) in (("f8_3", (64, 512)), ("f8_4", (128, 1024))):
                 off, n = self.offsets[nm]
                 P["w"][nm] = mirror[off:off + n].view(co, 1, ci)
-            # f9: input columns re-ordered to the internal feature layout [f8_3 | f8_4 | x_s | pad]
-            w9 = net.f9.weight.detach().reshape(192, 195)
-            w9p = torch.cat([w9[:, 3:67], w9[:, 67:195], w9[:, 0:3]], dim=1).contiguous()
-            wf = torch.empty(192, 1, FEAT_LD, device=device, dtype=tdt)
-            wt = torch.empty(FEAT_LD, 1, 192, device=device, dtype=tdt)
-            L.pack_weights(w9p, wf, wt, 192, 1, 195, 192, FEAT_LD, pdt)
+            # f9: input columns re-ordered to the internal feature layout [f8_3 | f8_4 | x_s | pad] = the master's columns rotated by 3
+            off9, n9 = self.offsets["f9"]
+            wf, wt = hb[3], hb[4]
+            L.pack_weights(self.flat_w[off9:off9 + n9], wf, wt, 192, 1, 195, 192, FEAT_LD, pdt, ic_rot=3)
             if dt == L.F32X3:
                 wf, wt = self._x3(wf), self._x3(wt)
             P["w"]["f9"], P["wt"]["f9"] = wf, wt
@@ -374,15 +376,63 @@ class Engine:
             L.pack_transposed_batch(self.flat_w, self.flat_wt, self._wt_table, self._wt_table.shape[0], self._wt_tiles, L.F32 if dt == L.F32X3 else dt)
             if dt == L.F32X3:
                 L.pack_x3(self.flat_wt, self.flat_wt3)
+        if dt == L.BF16 and any(k.endswith(".skip_fused") for k in P["w"]):
+            # the K-concatenated backward packs of the two-source launches, one launch from the transposed packs just made.  b5 (res):
+            # d_t = dgrad_3x3(du; W_2a) + D . W_branch1 — nine taps of du, then one K segment of D; b6 / b7 (bot): d_t = D . W_branch1 + du1 . W_branch2a
+            plan = self._fused_plan(self.flat_wt.device)
+            for nm, buf in plan["bwd_bufs"].items():
+                P["wt"][nm + ".skip_fused"] = buf
+            L.copy2d_batch(self.flat_wt, plan["bwd_flat"], plan["bwd_table"], plan["bwd_table"].shape[0], plan["bwd_chunks"])
+
+    def _fused_blocks(self):
+        """[(name, kind, cin, mid, cout)] of the blocks whose skip conv and last conv run as one two-source launch (bf16 mode)"""
+        out = []
         for b in arch.BLOCKS:
-            nm, cin_, mid_, cout_ = b[0], b[2], b[3], b[4]
-            if (nm + ".skip_fused") not in P["w"]:
+            nm, kind, cin_, mid_, cout_, stride = b[0], b[1], b[2], b[3], b[4], b[5]
+            if nm in arch.FROZEN_BLOCKS or stride != 1 or cout_ % 256:
                 continue
-            if b[1] == "res":     # d_t = dgrad_3x3(du; W_2a) + D . W_branch1: nine taps of du, then one K segment of D
-                wt = torch.cat([P["wt"][nm + ".conv_branch2a"].reshape(cin_, 9 * mid_), P["wt"][nm + ".conv_branch1"].reshape(cin_, cout_)], dim=1)
-            else:                 # d_t = D . W_branch1 + du1 . W_branch2a  (transposed packs [cin][1][cout] | [cin][1][cout/4])
-                wt = torch.cat([P["wt"][nm + ".conv_branch1"], P["wt"][nm + ".conv_branch2a"]], dim=2)
-            P["wt"][nm + ".skip_fused"] = wt
+            if kind == "res" and not arch.block_same_shape(b) and cin_ % 256 == 0:
+                out.append((nm, kind, cin_, mid_, cout_))
+            elif kind != "res" and cin_ == cout_ // 2:
+                out.append((nm, kind, cin_, mid_, cout_))
+        return out
+
+    def _fused_plan(self, device):
+        """Persistent K-concatenated pack buffers + the piece tables of wseg_copy2d_batch (16-byte = 8-element units), built once per device."""
+        plan = getattr(self, "_fused", None)
+        if plan is not None and plan["device"] == device:
+            return plan
+
+        def build(pieces_of):
+            rows_tab, bufs, sizes, chunk0, base = [], {}, [], 0, 0
+            for (nm, kind, cin_, mid_, cout_) in self._fused_blocks():
+                nrows, width, pieces = pieces_of(nm, kind, cin_, mid_, cout_)       # pieces: (param name, cols, column offset)
+                for (pname, cols, coff) in pieces:
+                    off, n = self.offsets[pname]
+                    assert n == nrows * cols and off % 8 == 0 and cols % 8 == 0 and coff % 8 == 0 and width % 8 == 0 and base % 8 == 0
+                    rows_tab.append([chunk0, off // 8, (base + coff) // 8, nrows, cols // 8, cols // 8, width // 8])
+                    chunk0 += nrows * (cols // 8)
+                sizes.append((nm, base, nrows, width))
+                base += nrows * width
+            flat = torch.empty(base, device=device, dtype=torch.bfloat16)
+            for nm, b0, nrows, width in sizes:
+                bufs[nm] = flat[b0:b0 + nrows * width].view(nrows, width)
+            return flat, bufs, torch.tensor(rows_tab, dtype=torch.int64, device=device), chunk0
+
+        def fwd_pieces(nm, kind, cin_, mid_, cout_):
+            if kind == "res":
+                return cout_, 9 * mid_ + cin_, [(nm + ".conv_branch2b1", 9 * mid_, 0), (nm + ".conv_branch1", cin_, 9 * mid_)]
+            return cout_, cin_ + cout_ // 2, [(nm + ".conv_branch1", cin_, 0), (nm + ".conv_branch2b2", cout_ // 2, cin_)]
+
+        def bwd_pieces(nm, kind, cin_, mid_, cout_):          # transposed packs [cin][T][cout']: rows = cin
+            if kind == "res":
+                return cin_, 9 * mid_ + cout_, [(nm + ".conv_branch2a", 9 * mid_, 0), (nm + ".conv_branch1", cout_, 9 * mid_)]
+            return cin_, cout_ + cout_ // 4, [(nm + ".conv_branch1", cout_, 0), (nm + ".conv_branch2a", cout_ // 4, cout_)]
+
+        ff, fb, ft, fc = build(fwd_pieces)
+        bf, bb, bt, bc = build(bwd_pieces)
+        self._fused = dict(device=device, fwd_flat=ff, fwd_bufs=fb, fwd_table=ft, fwd_chunks=fc, bwd_flat=bf, bwd_bufs=bb, bwd_table=bt, bwd_chunks=bc)
+        return self._fused
 
     # ------------------------------------------------------------------ dropout
     MASK_SPECS = (("b6.dropout_2b1", 512, 0.3), ("b6.dropout_2b2", 1024, 0.3),
@@ -596,7 +646,7 @@ class Engine:
         M = rows_of(dims)
         offs = offs_of(dims)
         head = E(M, HEAD_LD)
-        conv(fea, "head", head, None, 4096, HEAD_LD, 1, 1, 1, dims, dims, relu_lt=128)
+        conv(fea, "head", head, None, 4096, HEAD_LD, 1, 1, 1, dims, dims, relu_lt=128, w_rows=256)
         feat = E(M, FEAT_LD)
         conv(conv4, "f8_3", feat, None, 512, 64, 1, 1, 1, dims, dims, epi=2, ld_out=FEAT_LD)
         conv(conv5, "f8_4", feat.view(-1)[64:], None, 1024, 128, 1, 1, 1, dims, dims, epi=2, ld_out=FEAT_LD)
@@ -615,12 +665,16 @@ class Engine:
         Fh = torch.empty(M, 192, device=dev, dtype=torch.float32)
         nrm = torch.empty(M, device=dev, dtype=torch.float32)
         L.l2norm_forward(Fm, 192, Fh, nrm, M)
-        Fb = Gb = None
+        Fb = Gb = Gl = None
         if dt == L.BF16:                                      # bf16-MFMA PCM (throughput mode); fp32 mode keeps the exact-f32 kernel
             Fb = torch.empty(M, 192, device=dev, dtype=torch.bfloat16)
             Gb = torch.empty(M, 32, device=dev, dtype=torch.bfloat16)
             L.to_bf16(Fh, Fb)
-            L.to_bf16(G, Gb)
+            if save:                                          # the backward pass takes the gate map as hi + lo (split precision, csrc/pcm.hip)
+                Gl = torch.empty(M, 32, device=dev, dtype=torch.bfloat16)
+                L.split_bf16(G, Gb, Gl)
+            else:
+                L.to_bf16(G, Gb)
         outs = []
         for vw, x in zip(views, xs):
             h, w, off, hw = vw["h"], vw["w"], vw["off"], vw["h"] * vw["w"]
@@ -646,7 +700,7 @@ class Engine:
         if save and self.capture_ctx:
             self.last_ctx = S
         if save:
-            S.update(fea=fea, head=head, G=G, feat=feat, Fm=Fm, Fh=Fh, Fb=Fb, Gb=Gb, nrm=nrm, conv4=conv4, conv5=conv5,
+            S.update(fea=fea, head=head, G=G, feat=feat, Fm=Fm, Fh=Fh, Fb=Fb, Gb=Gb, Gl=Gl, nrm=nrm, conv4=conv4, conv5=conv5,
                      views=views, hdims=dims, M=M)
         return outs, S
 
@@ -795,24 +849,24 @@ class Engine:
                 DN = torch.empty(M, 32, device=dev, dtype=torch.float32)
                 dFh = torch.zeros(M, 192, device=dev, dtype=torch.float32)
                 DNb = torch.empty(M, 32, device=dev, dtype=torch.bfloat16) if S["Fb"] is not None else None
+                DNl = torch.empty(M, 32, device=dev, dtype=torch.bfloat16) if S["Fb"] is not None else None
                 for vw, dr in zip(S["views"], d_rvd):
                     if dr is None:
                         continue
                     off, hw = vw["off"], vw["h"] * vw["w"]
                     if S["Fb"] is not None:
-                        L.pcm_backward_bf16(S["Fb"][off:], S["Gb"][off:], dr.contiguous(), vw["rvd"], vw["den"], DN[off:], DNb[off:], dFh[off:], N, hw)
+                        L.pcm_backward_bf16(S["Fb"][off:], S["Gb"][off:], S["Gl"][off:], dr.contiguous(), vw["rvd"], vw["den"], DN[off:], DNb[off:],
+                                            DNl[off:], dFh[off:], N, hw)
                     else:
                         L.pcm_backward(S["Fh"][off:], S["G"][off:], dr.contiguous(), vw["rvd"], vw["den"], DN[off:], dFh[off:], N, hw)
                 dF = E(M, 192)
                 L.l2norm_backward(S["Fm"], 192, dFh, S["nrm"], dF, 192, M)
                 if trainable("f9"):
-                    g9 = torch.zeros(192, 195, device=dev, dtype=torch.float32)
-                    L.conv_wgrad(S["feat"], dF, g9, N=N, IH=hdims[0][0], IW=hdims[0][1], IC=FEAT_LD, OH=hdims[0][0], OW=hdims[0][1], OC=192,
-                                 KH=1, KW=1, IC_dw=195, seg2=seg(hdims, hdims), dtype=_cdt(dt))
-                    gv = self.grad_view("f9").reshape(192, 195)
-                    gv[:, 3:67] += g9[:, 0:64]
-                    gv[:, 67:195] += g9[:, 64:192]
-                    gv[:, 0:3] += g9[:, 192:195]
+                    # feature rows are [f8_3 64 | f8_4 128 | x_s 3 | pad], f9.weight's columns [x_s | f8_3 | f8_4]: the weight-gradient kernel rotates
+                    # its dW columns by 3 and accumulates straight into the flat gradient buffer (no staging tensor, no slice adds)
+                    off9, n9 = self.offsets["f9"]
+                    L.conv_wgrad(S["feat"], dF, self.flat_g[off9:off9 + n9], N=N, IH=hdims[0][0], IW=hdims[0][1], IC=FEAT_LD, OH=hdims[0][0],
+                                 OW=hdims[0][1], OC=192, KH=1, KW=1, IC_dw=195, seg2=seg(hdims, hdims), dtype=_cdt(dt), dw_rot=3)
                 if trainable("f8_3") or trainable("f8_4"):
                     d_feat = E(M, FEAT_LD)
                     dgrad(dF, "f9", d_feat, FEAT_LD, 192, 1, 1, 1, hdims, hdims, epi=1, mask=S["feat"])

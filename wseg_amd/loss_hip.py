@@ -348,9 +348,6 @@ def step(model, img1, img2, label20, bg_threshold=0.20, rng=None, rng_parity=Fal
     eng.run_backward(ctx, [(None, v.d_rvd, None, None) for v in views], d_head_rows=d_head)
     if eng.capture_ctx:                                     # tests: pseudo-labels, prototypes, hard-pixel weights of both views
         eng.last_loss_views = views
-    loss_cls = acc[0] * 0.5 + acc[1]
-    loss_er = acc[2] * er_coef
-    loss_ecr = acc[3]
-    loss_nce = acc[4] + acc[5] + acc[6]
-    return dict(loss=loss_cls + loss_er + loss_ecr + loss_nce, loss_cls=loss_cls, loss_er=loss_er, loss_ecr=loss_ecr,
-                loss_nce=loss_nce, loss_intra_nce=acc[6], loss_cross_nce=acc[4], loss_cross_nce2=acc[5])
+    out8 = torch.empty(8, device=dev, dtype=torch.float32)
+    L.loss_finish(acc, er_coef, out8)
+    return dict(zip(("loss", "loss_cls", "loss_er", "loss_ecr", "loss_nce", "loss_intra_nce", "loss_cross_nce", "loss_cross_nce2"), out8.unbind(0)))
