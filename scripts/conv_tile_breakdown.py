@@ -22,6 +22,10 @@ SHAPES = [("512->512 3x3 56^2", 56, 512, 512, 3, 1), ("256->256 3x3 112^2", 112,
 def main():
     dev, N = "cuda", 16
     only = [a[7:] for a in sys.argv if a.startswith("--only=")]
+    for a in sys.argv:
+        if a.startswith("--diag="):      # probe-only timing switches (wrong results): 1 = A requested every 9th K-tile, 2 = no B requests, 4 = no A requests
+            L.debug_set_diag(int(a[7:]))
+            print("diag", a[7:])
     for name, H, IC, OC, k, d in SHAPES:
         if only and not any(o in name for o in only):
             continue
@@ -30,6 +34,10 @@ def main():
         M = N * (H * H + H2 * H2)
         x = torch.randn(M, IC, device=dev).bfloat16()
         w = (torch.randn(OC, k * k, IC, device=dev) * 0.02).bfloat16()
+        if "--zero" in sys.argv:         # all-zero operands: the chip holds its top clock, so us per K-tile ranks loops by CYCLES (MI355X_MICROARCH.md, DVFS give-back)
+            x.zero_(); w.zero_()
+        if "--relu" in sys.argv:         # activations as the network has them: non-negative, half of them zero
+            x.relu_()
         res = torch.randn(M, OC, device=dev).bfloat16()
         mask = torch.randn(M, OC, device=dev).bfloat16()
         out, out2 = torch.empty(M, OC, device=dev, dtype=torch.bfloat16), torch.empty(M, OC, device=dev, dtype=torch.bfloat16)
@@ -66,8 +74,12 @@ def main():
                   f"first-DMA wait {med(wait):5.2f}  main loop {med(loop):6.2f} ({med(loop) / nk:5.3f}/K-tile)  epilogue {med(epi):5.2f} (late waves {med(epi_late):5.2f}) us | "
                   f"round-1 tiles end at {med(st[first, 4]):6.1f} +- {float(np.std(st[first, 4])):4.1f} us"
                   + (f", later tiles start {med(st[rest, 0]):6.1f}, end {med(st[rest, 4]):6.1f} +- {float(np.std(st[rest, 4])):4.1f} us; last end {float(st[:, 4].max()):6.1f}" if len(rest) else ""), flush=True)
-            if raw[:, 8:].any():             # WSEG_PROBES=2 build: cycles per K-tile in each slot of the main loop, waves 0 (early group) and 4 (late group)
-                names = ["read1", "bar", "mfma1", "bar", "read2+wait", "bar", "mfma2", "bar"]
+            if raw[:, 8:10].all() and not raw[:, 10:].any():   # WSEG_PROBES=1 build: shader-clock stamps around the main loop of wave 0
+                cyc = raw[:, 9] - raw[:, 8]
+                print(f"    main loop: {med(cyc) / nk:6.0f} cycles per K-tile at {med(cyc / (loop * 1e-6)) / 1e9:5.3f} GHz", flush=True)
+            elif raw[:, 8:].any():             # WSEG_PROBES=2 build: cycles per K-tile in each slot of the main loop, waves 0 (early group) and 4 (late group)
+                names = ["read1", "bar", "mfma1", "bar", "read2+wait", "bar", "mfma2", "bar"] if os.environ.get("WSEG_CONV_LOOP", "1") == "0" else \
+                        ["compute", "dma-wait", "barrier", "-", "-", "-", "-", "-"]
                 for wv, lo in ((0, 8), (4, 16)):
                     cyc = np.median(raw[:, lo:lo + 8], axis=0) / nk
                     print(f"    wave {wv}: cycles per K-tile  " + "  ".join(f"{n_} {c:6.0f}" for n_, c in zip(names, cyc)) + f"   total {cyc.sum():6.0f}", flush=True)

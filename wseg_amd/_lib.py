@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libwseg_hip.so")
+LIB_PATH = os.environ.get("WSEG_LIB") or os.path.join(_HERE, "libwseg_hip.so")   # (WSEG_LIB: a probe build kept beside the product, development only)
 
 F32, BF16, F32X3 = 0, 1, 2      # F32X3: f32 tensors, conv / wgrad products as split-bf16 (hi.hi + lo.hi + hi.lo)
 PROFILE_WGRAD = None
@@ -373,6 +373,13 @@ def debug_stamps(n_wg):
     lib.wseg_debug_stamps.argtypes = [C.c_void_p, C.c_size_t]
     check(lib.wseg_debug_stamps(buf.ctypes.data_as(C.c_void_p), C.c_size_t(buf.nbytes)), "wseg_debug_stamps")
     return buf
+
+
+def debug_set_diag(v):
+    """probe builds: timing switches of the 256-tile conv main loop (results wrong by design; csrc/conv_igemm.hip g_wseg_diag)"""
+    if not hasattr(lib, "wseg_debug_set_diag"):
+        raise RuntimeError("wseg_debug_set_diag exists in probe builds only")
+    check(lib.wseg_debug_set_diag(int(v)), "wseg_debug_set_diag")
 
 
 def to_bf16(inp, out): _call("wseg_to_bf16", _v(inp), _v(out), C.c_long(inp.numel()))

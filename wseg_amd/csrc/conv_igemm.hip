@@ -33,8 +33,25 @@ __device__ unsigned long long g_wseg_stamps[24 * 4096];   // per workgroup: 8 wa
 extern "C" int wseg_debug_stamps(void* out, size_t bytes) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wseg_stamps), bytes < sizeof(g_wseg_stamps) ? bytes : sizeof(g_wseg_stamps)) == hipSuccess ? 0 : -1;
 }
+#define WSEG_CSTAMP(slot, wave)   /* shader-clock stamp (s_memtime): with the wall-clock stamps beside it, the clock the loop ran at */ \
+  do { if (threadIdx.x == (wave) * 64 && bid < 4096) g_wseg_stamps[bid * 24 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+// probe-only timing switches (results wrong by design): bit 0 = request the A tile only on every 9th K-tile, bit 1 = no B requests after the prologue,
+// bit 2 = no A requests after the prologue, bit 3 = the A pointers never move (every request re-reads the tile's first K-tile: cache-resident), bit 4 = the same for B
+__device__ int g_wseg_diag;
+extern "C" int wseg_debug_set_diag(int v) { return hipMemcpyToSymbol(HIP_SYMBOL(g_wseg_diag), &v, sizeof(int)) == hipSuccess ? 0 : -1; }
+#define WSEG_DIAG_LOAD() const int diag_ = __builtin_amdgcn_readfirstlane(g_wseg_diag)
+#define WSEG_DIAG_A_OK(u) (!(diag_ & 4) && (!(diag_ & 1) || (u) % 9 == 8))
+#define WSEG_DIAG_B_OK() (!(diag_ & 2))
+#define WSEG_DIAG_A_MOVES() (!(diag_ & 8))
+#define WSEG_DIAG_B_MOVES() (!(diag_ & 16))
 #else
 #define WSEG_STAMP(slot, wave) do { } while (0)
+#define WSEG_CSTAMP(slot, wave) do { } while (0)
+#define WSEG_DIAG_LOAD() do { } while (0)
+#define WSEG_DIAG_A_OK(u) true
+#define WSEG_DIAG_B_OK() true
+#define WSEG_DIAG_A_MOVES() true
+#define WSEG_DIAG_B_MOVES() true
 #endif
 // WSEG_SLOTS (with WSEG_PROBES): cycles (s_memtime) a wave spends in each slot of the main loop, summed over the K-tiles: read slot 1 (fragment reads
 // until they have landed + LDS-DMA issue), barrier, MFMA slot 1, barrier, read slot 2 (+ the counted DMA wait), barrier, MFMA slot 2, barrier.
@@ -606,7 +623,7 @@ constexpr int HALF256 = 16384, TILE256 = 4 * HALF256;
 // b[0] / b[1] that hold the two K halves in bf16 mode hold (hi, lo) here, and a quadrant issues lo.hi + hi.lo + hi.hi.
 // The tile body is a device function of (arguments, the workgroup's 128 KiB LDS buffer, block id): `conv_igemm256_kernel` is one workgroup = one
 // tile; `conv_bwd_pair_kernel` (below) runs it in the first workgroups of a grid whose other workgroups run the weight-gradient tile body.
-template <int EPI, int NI = 8, int DT = WSEG_BF16>
+template <int EPI, int NI = 8, int DT = WSEG_BF16, bool TAPF = true>
 __device__ __forceinline__ void conv_igemm256_tile(const Args& a, char* smem, const int bid) {
   constexpr bool X3 = DT == WSEG_F32X3;
   constexpr int ES = X3 ? 4 : 2, CH = 16 / ES;
@@ -621,6 +638,7 @@ __device__ __forceinline__ void conv_igemm256_tile(const Args& a, char* smem, co
   const int wr = wid >> 2, wc = wid & 3;
   const int frow = lane & 15, fk = lane >> 4, sw = (lane >> 1) & 7;
   WSEG_STAMP(0, 0);
+  WSEG_DIAG_LOAD();
 
   const char* zero = reinterpret_cast<const char*>(g_wseg_zero_page);
   const char* IN = reinterpret_cast<const char*>(d.in);
@@ -668,20 +686,49 @@ __device__ __forceinline__ void conv_igemm256_tile(const Args& a, char* smem, co
   const int nt = d.in2 != nullptr ? (ntaps - 1) * a.cpt + a.cpt2 : ntaps * a.cpt;
   issue_b(0, 0); issue_b(1, 0); advance_b();
   if (nt > 1) { issue_b(0, 1); issue_b(1, 1); advance_b(); }
-  int a_base[4], a_yx[4];
+  // Per-row gather state, two words.  TAPF (every launch but the strided data gradient): the row's ORIGIN input pixel (tap (0, 0); possibly outside the
+  // tensor, never dereferenced then) and a mask of the taps that fall inside the image — bit ky: row iy0 +- ky*dil is in [0, H), bit 8 + kx: the same
+  // for the column, bit 16: second row segment.  A tap switch is then a uniform pixel offset per segment, two bit tests and one 64-bit multiply-add per
+  // row (the full decode per tap — unpack, four compares, the stride arithmetic — measured ~1900 cycles per switch with every wave of the tile in it at
+  // once: 9 % of a 512-channel and 16 % of a 256-channel 3x3 layer's main loop, profiles/r03_conv_tap_setup.txt).  !TAPF (stride-2 data gradient, rows in
+  // parity-class order: three launches per step): first input row (-1 beyond M) + packed {segment | iy0 | ix0}, decoded in full at every switch.
+  int a_w0[4], a_w1[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int rho = r0 + 64 * (j & 1);             // LDS row inside half-slot j >> 1 = tile row (j >> 1) * RH + rho
     const int m = m0 + (j >> 1) * RH + rho;
-    if (rho < RH && m < a.M) {
-      const wseg_rowgeo rg = a.perm ? perm_decode(a, m).g : wseg_decode_row(d, m);
-      int iy0, ix0;
-      if (d.mode == 0) { iy0 = rg.oy * d.stride - d.pad; ix0 = rg.ox * d.stride - d.pad; }
-      else             { iy0 = rg.oy + d.pad;            ix0 = rg.ox + d.pad; }
-      a_base[j] = (int)rg.in_base;
-      a_yx[j] = (rg.n_glob >= d.N ? (int)0x80000000 : 0) | ((iy0 + 0x2000) << 16) | (ix0 + 0x2000);
+    if constexpr (TAPF) {
+      a_w0[j] = 0; a_w1[j] = 0;
+      if (rho < RH && m < a.M) {
+        const wseg_rowgeo rg = wseg_decode_row(d, m);
+        const int sg = d.mode == 0 ? d.dil : -d.dil;
+        const int iy0 = d.mode == 0 ? rg.oy * d.stride - d.pad : rg.oy + d.pad, ix0 = d.mode == 0 ? rg.ox * d.stride - d.pad : rg.ox + d.pad;
+        unsigned mk = rg.n_glob >= d.N ? 0x10000u : 0u;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {              // (k >= KH / KW: a bit no tap tests)
+          if ((unsigned)(iy0 + k * sg) < (unsigned)rg.IH) mk |= 1u << k;
+          if ((unsigned)(ix0 + k * sg) < (unsigned)rg.IW) mk |= 0x100u << k;
+        }
+        if (d.KH > 3 || d.KW > 3) {                // (KH, KW <= 8: host-checked; no layer of this network)
+          for (int k = 3; k < 8; ++k) {
+            if ((unsigned)(iy0 + k * sg) < (unsigned)rg.IH) mk |= 1u << k;
+            if ((unsigned)(ix0 + k * sg) < (unsigned)rg.IW) mk |= 0x100u << k;
+          }
+        }
+        a_w0[j] = (int)rg.in_base + iy0 * rg.IW + ix0;
+        a_w1[j] = (int)mk;
+      }
     } else {
-      a_base[j] = -1; a_yx[j] = (0x2000 << 16) | 0x2000;
+      if (rho < RH && m < a.M) {
+        const wseg_rowgeo rg = a.perm ? perm_decode(a, m).g : wseg_decode_row(d, m);
+        int iy0, ix0;
+        if (d.mode == 0) { iy0 = rg.oy * d.stride - d.pad; ix0 = rg.ox * d.stride - d.pad; }
+        else             { iy0 = rg.oy + d.pad;            ix0 = rg.ox + d.pad; }
+        a_w0[j] = (int)rg.in_base;
+        a_w1[j] = (rg.n_glob >= d.N ? (int)0x80000000 : 0) | ((iy0 + 0x2000) << 16) | (ix0 + 0x2000);
+      } else {
+        a_w0[j] = -1; a_w1[j] = (0x2000 << 16) | 0x2000;
+      }
     }
   }
   const char* aptr[4];
@@ -693,6 +740,20 @@ __device__ __forceinline__ void conv_igemm256_tile(const Args& a, char* smem, co
     const char* INs = src2 ? reinterpret_cast<const char*>(d.in2) + lc * 16 : INl;
     const int lds = src2 ? d.ld_in2 : d.ld_in;
     a_live = 0;
+    if constexpr (TAPF) {
+      const int sg = d.mode == 0 ? d.dil : -d.dil;
+      const int dp1 = sg * (ky * d.IW + kx), dp2 = sg * (ky * d.IW2 + kx);   // pixel offset of the tap in segment 1 / 2 (uniform)
+      const long rowb = (long)lds * ES;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned vm = (unsigned)a_w1[j];
+        const bool ok = ((vm >> ky) & (vm >> (8 + kx)) & 1u) != 0;
+        const int pix = a_w0[j] + ((vm & 0x10000u) ? dp2 : dp1);
+        aptr[j] = ok ? INs + (long)pix * rowb : zsrc;
+        a_live |= ok ? 1u << j : 0u;
+      }
+    } else {
+      const int (&a_base)[4] = a_w0; const int (&a_yx)[4] = a_w1;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int iy0 = ((a_yx[j] >> 16) & 0x7FFF) - 0x2000, ix0 = (a_yx[j] & 0xFFFF) - 0x2000;
@@ -710,6 +771,7 @@ __device__ __forceinline__ void conv_igemm256_tile(const Args& a, char* smem, co
       ok = ok && iy >= 0 && iy < H && ix >= 0 && ix < W;
       if (ok) { aptr[j] = INs + (size_t)(a_base[j] + iy * W + ix) * lds * ES; a_live |= 1u << j; }
       else    { aptr[j] = zsrc; }
+    }
     }
   };
   int a_tap = 0, a_cc = 0;                         // position of the NEXT A tile to issue
@@ -736,6 +798,9 @@ __device__ __forceinline__ void conv_igemm256_tile(const Args& a, char* smem, co
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   WSEG_STAMP(2, 0);
+#ifndef WSEG_SLOTS
+  WSEG_CSTAMP(8, 0);
+#endif
 
   bf16x8 af[2][4], b0[2][2], b1[2][2];             // [ks][tile]: A sub-tile (64 rows), B sub-tiles hb = 0 / 1 (32 cols each)
   auto ldA = [&](const char* aH, int ha) {
@@ -805,21 +870,26 @@ __device__ __forceinline__ void conv_igemm256_tile(const Args& a, char* smem, co
       //  64-127 in slot 2, the requests in front of the reads or behind an lgkmcnt(0): 1.29-1.37 us per K-tile against 1.31 — the sum of the two
       //  read slots stays above the sum of the MFMA slots whatever their split; profiles/HISTORY.md.)
       ldA(aH, 0); ldB(bH, 0, b0); ldB(bH, 1, b1);
-      if (u + 1 < nt) { issue_a(0, b ^ 1); issue_a(1, b ^ 1); advance_a(); }
+      if (u + 1 < nt && WSEG_DIAG_A_OK(u)) { issue_a(0, b ^ 1); issue_a(1, b ^ 1); }
       WSEG_SLOT(0);
       __builtin_amdgcn_s_barrier();
       WSEG_SLOT(1);
+      // (the A pointers move on — and, at the end of a tap, are set up for the next one — inside an MFMA slot whose partner slot is longer: the early group's
+      //  slot 1 runs beside the late group's read slot 1, the late group's slot 2 beside the early group's next read slot 1; in the read slot, where the
+      //  pointers were advanced until round 3, every cycle of the tap switch was a cycle of the matrix pipe waiting)
+      if (wr == 0 && u + 1 < nt && WSEG_DIAG_A_MOVES()) advance_a();
       MFMA_Q(0, 0, b0);
       MFMA_Q(0, 1, b1);
       WSEG_SLOT(2);
       __builtin_amdgcn_s_barrier();
       WSEG_SLOT(3);
       ldA(aH, 1);
-      if (u + 2 < nt) { issue_b(0, b); issue_b(1, b); advance_b(); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+      if (u + 2 < nt) { if (WSEG_DIAG_B_OK()) { issue_b(0, b); issue_b(1, b); } if (WSEG_DIAG_B_MOVES()) advance_b(); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       WSEG_SLOT(4);
       __builtin_amdgcn_s_barrier();
       WSEG_SLOT(5);
+      if (wr == 1 && u + 1 < nt && WSEG_DIAG_A_MOVES()) advance_a();
       MFMA_Q(1, 1, b1);
       MFMA_Q(1, 0, b0);
       WSEG_SLOT(6);
@@ -833,6 +903,9 @@ __device__ __forceinline__ void conv_igemm256_tile(const Args& a, char* smem, co
 
   // ---- epilogue, wave-local (see wave_local_epilogue)
   WSEG_STAMP(3, 0); WSEG_STAMP(5, 4);
+#ifndef WSEG_SLOTS
+  WSEG_CSTAMP(9, 0);
+#endif
   __syncthreads();                                 // every wave is done with the pipeline buffers
   wave_local_epilogue<EPI, NI, DT>(a, smem, wid, lane, m0 + wr * RH, wc * 64, n0, acc);
 #ifdef WSEG_PROBES
@@ -842,10 +915,10 @@ __device__ __forceinline__ void conv_igemm256_tile(const Args& a, char* smem, co
 #endif
 }
 
-template <int EPI, int NI = 8, int DT = WSEG_BF16>
+template <int EPI, int NI = 8, int DT = WSEG_BF16, bool TAPF = true>
 __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const Args a) {
   __shared__ __attribute__((aligned(16))) char smem[2 * TILE256];
-  conv_igemm256_tile<EPI, NI, DT>(a, smem, blockIdx.x);
+  conv_igemm256_tile<EPI, NI, DT, TAPF>(a, smem, blockIdx.x);
 }
 
 
@@ -1088,7 +1161,7 @@ static bool conv_plan_256(const wseg_conv_desc* d, Args& a, bool& ni7) {
   // (OC % 256 != 0: only with a weight pack zero-padded to whole 256-row tiles, wseg_conv_desc.w_rows — the epilogue masks the columns >= OC)
   const bool oc_ok = d->OC % 256 == 0 || (d->in2 == nullptr && d->w_rows >= ((d->OC + 255) / 256) * 256);
   if (!((d->dtype == WSEG_BF16 || (d->dtype == WSEG_F32X3 && d->in2 == nullptr)) && oc_ok && d->bm_hint != 64 && d->bm_hint != 128 &&
-        d->bm_hint != 259 && d->bm_hint >= 0))
+        d->bm_hint != 259 && d->bm_hint >= 0 && d->KH <= 8 && d->KW <= 8 && a.taps <= 16))   // (tap list: 16 four-bit entries; tap masks: 8 + 8 bits)
     return false;
   static const int auto256 = getenv("WSEG_CONV256") ? atoi(getenv("WSEG_CONV256")) : 1;   // (0: A/B switch — 128-tile kernel everywhere)
   if (!(d->bm_hint == 256 || d->bm_hint == 224 || d->in2 != nullptr || (auto256 && conv_cost_prefers_256(M, d->OC)))) return false;
@@ -1154,14 +1227,20 @@ extern "C" int wseg_conv_igemm(const wseg_conv_desc* d, void* stream) {
     return 0;
   }
   if (big) {
-#define WSEG_LAUNCH_256(NI_, DT_)                                                                                              \
+#define WSEG_LAUNCH_256(NI_, DT_, TF_)                                                                                         \
   do {                                                                                                                         \
-    if (d->epi == 0) hipLaunchKernelGGL((conv_igemm256_kernel<0, NI_, DT_>), dim3(a.nwg), dim3(512), 0, s, a);                  \
-    else if (d->epi == 1) hipLaunchKernelGGL((conv_igemm256_kernel<1, NI_, DT_>), dim3(a.nwg), dim3(512), 0, s, a);             \
-    else hipLaunchKernelGGL((conv_igemm256_kernel<2, NI_, DT_>), dim3(a.nwg), dim3(512), 0, s, a);                              \
+    if (d->epi == 0) hipLaunchKernelGGL((conv_igemm256_kernel<0, NI_, DT_, TF_>), dim3(a.nwg), dim3(512), 0, s, a);             \
+    else if (d->epi == 1) hipLaunchKernelGGL((conv_igemm256_kernel<1, NI_, DT_, TF_>), dim3(a.nwg), dim3(512), 0, s, a);        \
+    else hipLaunchKernelGGL((conv_igemm256_kernel<2, NI_, DT_, TF_>), dim3(a.nwg), dim3(512), 0, s, a);                         \
   } while (0)
-    if (d->dtype == WSEG_F32X3) { if (ni7) WSEG_LAUNCH_256(7, WSEG_F32X3); else WSEG_LAUNCH_256(8, WSEG_F32X3); }
-    else { if (ni7) WSEG_LAUNCH_256(7, WSEG_BF16); else WSEG_LAUNCH_256(8, WSEG_BF16); }
+    const bool tapf = !(d->mode == 1 && d->stride != 1);      // (the strided data gradient keeps the full per-tap decode: conv_igemm256_tile)
+    if (d->dtype == WSEG_F32X3) {
+      if (tapf) { if (ni7) WSEG_LAUNCH_256(7, WSEG_F32X3, true); else WSEG_LAUNCH_256(8, WSEG_F32X3, true); }
+      else      { if (ni7) WSEG_LAUNCH_256(7, WSEG_F32X3, false); else WSEG_LAUNCH_256(8, WSEG_F32X3, false); }
+    } else {
+      if (tapf) { if (ni7) WSEG_LAUNCH_256(7, WSEG_BF16, true); else WSEG_LAUNCH_256(8, WSEG_BF16, true); }
+      else      { if (ni7) WSEG_LAUNCH_256(7, WSEG_BF16, false); else WSEG_LAUNCH_256(8, WSEG_BF16, false); }
+    }
 #undef WSEG_LAUNCH_256
   } else if (small) {
     a.nwg = (int)(((M + 63) / 64) * a.ntn);
