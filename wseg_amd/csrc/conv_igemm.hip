@@ -733,26 +733,32 @@ __device__ __forceinline__ void conv_igemm256_tile(const Args& a, char* smem, co
   }
   const char* aptr[4];
   unsigned a_live = 0;                             // bit j: row j reads real data (pointer advances by 128 B per K-tile)
+  int a_tap = 0, a_cc = 0;                         // position of the NEXT A tile to issue
+  int a_ky = 0, a_kx = 0;                          // (TAPF) kernel coordinates of tap a_tap
   auto set_tap = [&](int tap) {
     const bool src2 = d.in2 != nullptr && tap == d.KH * d.KW;   // two sources: the extra last "tap" = the output pixel itself in the second input
-    const int tg = src2 ? (d.KH / 2) * d.KW + d.KW / 2 : tap;    // (its geometry is the centre tap's: same-size convolution, stride 1)
-    const int ky = tg / d.KW, kx = tg - ky * d.KW;
     const char* INs = src2 ? reinterpret_cast<const char*>(d.in2) + lc * 16 : INl;
     const int lds = src2 ? d.ld_in2 : d.ld_in;
     a_live = 0;
     if constexpr (TAPF) {
+      // (32-bit byte offsets: the host gives this instantiation only tensors below 2 GiB; one quarter-rate multiply and ~10 full-rate instructions per row)
+      const int tky = src2 ? d.KH / 2 : a_ky, tkx = src2 ? d.KW / 2 : a_kx;          // (taps come in natural order: no division)
       const int sg = d.mode == 0 ? d.dil : -d.dil;
-      const int dp1 = sg * (ky * d.IW + kx), dp2 = sg * (ky * d.IW2 + kx);   // pixel offset of the tap in segment 1 / 2 (uniform)
-      const long rowb = (long)lds * ES;
+      const int dp1 = sg * (tky * d.IW + tkx), dp2 = sg * (tky * d.IW2 + tkx);      // pixel offset of the tap in segment 1 / 2 (uniform)
+      const unsigned tmask = (1u << tky) | (0x100u << tkx);
+      const int rowb = lds * ES;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const unsigned vm = (unsigned)a_w1[j];
-        const bool ok = ((vm >> ky) & (vm >> (8 + kx)) & 1u) != 0;
-        const int pix = a_w0[j] + ((vm & 0x10000u) ? dp2 : dp1);
-        aptr[j] = ok ? INs + (long)pix * rowb : zsrc;
+        const bool ok = (vm & tmask) == tmask;
+        const int off = (a_w0[j] + ((vm & 0x10000u) ? dp2 : dp1)) * rowb;
+        const char* p = INs + (long)off;
+        aptr[j] = ok ? p : zsrc;
         a_live |= ok ? 1u << j : 0u;
       }
     } else {
+      const int tg = src2 ? (d.KH / 2) * d.KW + d.KW / 2 : tap;    // (its geometry is the centre tap's: same-size convolution, stride 1)
+      const int ky = tg / d.KW, kx = tg - ky * d.KW;
       const int (&a_base)[4] = a_w0; const int (&a_yx)[4] = a_w1;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -774,7 +780,6 @@ __device__ __forceinline__ void conv_igemm256_tile(const Args& a, char* smem, co
     }
     }
   };
-  int a_tap = 0, a_cc = 0;                         // position of the NEXT A tile to issue
   auto issue_a = [&](int h, int buf) {             // half h = rows [128h, 128h+128): this thread's rows 2h, 2h+1
     char* dst = smem + buf * TILE256 + h * HALF256 + wid * 1024;
     glds16(aptr[2 * h], dst);
@@ -783,7 +788,13 @@ __device__ __forceinline__ void conv_igemm256_tile(const Args& a, char* smem, co
   auto advance_a = [&]() {
 #pragma unroll
     for (int j = 0; j < 4; ++j) aptr[j] += ((a_live >> j) & 1u) << 7;
-    if (++a_cc == a.cpt) { a_cc = 0; if (++a_tap < ntaps) set_tap((int)((tl >> (4 * a_tap)) & 15ull)); }   // (two sources: the walk ends after cpt2 steps of source 2)
+    if (++a_cc == a.cpt) {
+      a_cc = 0;
+      if (++a_tap < ntaps) {                       // (two sources: the walk ends after cpt2 steps of source 2)
+        if (TAPF) { if (++a_kx == d.KW) { a_kx = 0; ++a_ky; } }
+        set_tap((int)((tl >> (4 * a_tap)) & 15ull));
+      }
+    }
   };
   f32x4 acc[NI][4];
 #pragma unroll
@@ -1233,7 +1244,9 @@ extern "C" int wseg_conv_igemm(const wseg_conv_desc* d, void* stream) {
     else if (d->epi == 1) hipLaunchKernelGGL((conv_igemm256_kernel<1, NI_, DT_, TF_>), dim3(a.nwg), dim3(512), 0, s, a);        \
     else hipLaunchKernelGGL((conv_igemm256_kernel<2, NI_, DT_, TF_>), dim3(a.nwg), dim3(512), 0, s, a);                         \
   } while (0)
-    const bool tapf = !(d->mode == 1 && d->stride != 1);      // (the strided data gradient keeps the full per-tap decode: conv_igemm256_tile)
+    const long es_ = d->dtype == WSEG_BF16 ? 2 : 4;
+    const long in_bytes = ((long)d->N * d->IH * d->IW + (long)d->N * d->IH2 * d->IW2) * std::max(d->ld_in, d->in2 ? d->ld_in2 : 0) * es_;
+    const bool tapf = !(d->mode == 1 && d->stride != 1) && in_bytes < (1L << 31) - (1L << 24);   // (else: the full per-tap decode with 64-bit addresses: conv_igemm256_tile)
     if (d->dtype == WSEG_F32X3) {
       if (tapf) { if (ni7) WSEG_LAUNCH_256(7, WSEG_F32X3, true); else WSEG_LAUNCH_256(8, WSEG_F32X3, true); }
       else      { if (ni7) WSEG_LAUNCH_256(7, WSEG_F32X3, false); else WSEG_LAUNCH_256(8, WSEG_F32X3, false); }
@@ -1266,6 +1279,8 @@ static int conv_bwd_pair_plan(const wseg_conv_desc* dg, const wseg_wgrad_desc* w
   const bool cand = pair_ok && dg->dtype == WSEG_BF16 && wg->dtype == WSEG_BF16 && dg->mode == 1 && dg->stride == 1 && dg->bm_hint == 0 &&
                     dg->out != nullptr && dg->out2 == nullptr && dg->epi >= 0 && dg->epi <= 2;
   if (!cand) return 0;
+  if (((long)dg->N * dg->IH * dg->IW + (long)dg->N * dg->IH2 * dg->IW2) * std::max(dg->ld_in, dg->in2 ? dg->ld_in2 : 0) * 2L >= (1L << 31) - (1L << 24))
+    return 0;                                      // (the joint grid carries the 32-bit tap arithmetic only)
   if (conv_validate(dg)) return 0;                 // (the fall-back launch reports the error)
   {
     // the two-source form errors out of conv_fill_args when it does not qualify: test its conditions first, quietly
