@@ -36,7 +36,7 @@ extern "C" int wseg_debug_stamps(void* out, size_t bytes) {
 #define WSEG_CSTAMP(slot, wave)   /* shader-clock stamp (s_memtime): with the wall-clock stamps beside it, the clock the loop ran at */ \
   do { if (threadIdx.x == (wave) * 64 && bid < 4096) g_wseg_stamps[bid * 24 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
 // probe-only timing switches (results wrong by design): bit 0 = request the A tile only on every 9th K-tile, bit 1 = no B requests after the prologue,
-// bit 2 = no A requests after the prologue, bit 3 = the A pointers never move (every request re-reads the tile's first K-tile: cache-resident), bit 4 = the same for B
+// bit 2 = no A requests after the prologue, bit 3 = the A pointers never move (every request re-reads the tile's first K-tile: cache-resident), bit 4 = the same for B, bit 5 = the wave-local epilogue stores nothing (its loads and LDS round trips stay), bit 6 = it loads nothing either
 __device__ int g_wseg_diag;
 extern "C" int wseg_debug_set_diag(int v) { return hipMemcpyToSymbol(HIP_SYMBOL(g_wseg_diag), &v, sizeof(int)) == hipSuccess ? 0 : -1; }
 #define WSEG_DIAG_LOAD() const int diag_ = __builtin_amdgcn_readfirstlane(g_wseg_diag)
@@ -44,6 +44,8 @@ extern "C" int wseg_debug_set_diag(int v) { return hipMemcpyToSymbol(HIP_SYMBOL(
 #define WSEG_DIAG_B_OK() (!(diag_ & 2))
 #define WSEG_DIAG_A_MOVES() (!(diag_ & 8))
 #define WSEG_DIAG_B_MOVES() (!(diag_ & 16))
+#define WSEG_DIAG_EPI_STORES() (!(__builtin_amdgcn_readfirstlane(g_wseg_diag) & 32))
+#define WSEG_DIAG_EPI_LOADS() (!(__builtin_amdgcn_readfirstlane(g_wseg_diag) & 64))
 #else
 #define WSEG_STAMP(slot, wave) do { } while (0)
 #define WSEG_CSTAMP(slot, wave) do { } while (0)
@@ -52,6 +54,8 @@ extern "C" int wseg_debug_set_diag(int v) { return hipMemcpyToSymbol(HIP_SYMBOL(
 #define WSEG_DIAG_B_OK() true
 #define WSEG_DIAG_A_MOVES() true
 #define WSEG_DIAG_B_MOVES() true
+#define WSEG_DIAG_EPI_STORES() true
+#define WSEG_DIAG_EPI_LOADS() true
 #endif
 // WSEG_SLOTS (with WSEG_PROBES): cycles (s_memtime) a wave spends in each slot of the main loop, summed over the K-tiles: read slot 1 (fragment reads
 // until they have landed + LDS-DMA issue), barrier, MFMA slot 1, barrier, read slot 2 (+ the counted DMA wait), barrier, MFMA slot 2, barrier.
@@ -276,8 +280,9 @@ __device__ __forceinline__ void wave_local_epilogue_batch(const Args& a, float* 
   const wseg_conv_desc& d = a.d;
   const int frow = lane & 15, fk = lane >> 4;
   const int vr = lane >> 3, vg = lane & 7;
-  const bool has_pre = d.r_pre != nullptr, has_post = d.r_post != nullptr, has_mask = EPI == 1 && d.mask != nullptr;
-  const bool has_drop = EPI != 2 && d.drop != nullptr;
+  const bool ld_ok_ = WSEG_DIAG_EPI_LOADS();       // (probe builds only: compiled out of the product)
+  const bool has_pre = d.r_pre != nullptr && ld_ok_, has_post = d.r_post != nullptr && ld_ok_, has_mask = EPI == 1 && d.mask != nullptr && ld_ok_;
+  const bool has_drop = EPI != 2 && d.drop != nullptr && ld_ok_;
   const bool res_is_pre = has_pre;                 // the prefetched residual: r_pre when present, else r_post
   const bool post_in_step = has_pre && has_post;
   const void* res_p = res_is_pre ? d.r_pre : d.r_post;
@@ -292,6 +297,7 @@ __device__ __forceinline__ void wave_local_epilogue_batch(const Args& a, float* 
       const int m = mw0 + (I0 + i) * 16 + vr + 8 * t;
       ok[i][t] = col_ok && m < a.M;
       mrow[i][t] = ok[i][t] ? (a.perm ? (int)perm_decode(a, m).true_row : m) : 0;
+      ok[i][t] = ok[i][t] && WSEG_DIAG_EPI_STORES();
       if (has_res) qres[i][t].load(res_p, (size_t)mrow[i][t] * res_ld + oc);
       if (has_mask) qmk[i][t].load(d.mask, (size_t)mrow[i][t] * d.ld_mask + oc);
     }
