@@ -4,7 +4,7 @@
 #   scripts/gpu.sh 1200 'bash scripts/refresh_profiles.sh'
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/refresh
-R=${WSEG_ROUND:-r02}
+R=${WSEG_ROUND:-r03}
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -o run -- python "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --parity-steps 0 > "$OUT/pmc_fetch.log" 2>&1 && echo "pmc fetch ok" &&

@@ -700,8 +700,12 @@ def test_lookahead_prefix_changes_nothing(proc_sd, prec):
     for j, (x, y) in enumerate(zip(a, b)):
         for k in SCALARS:
             if k in ("loss", "loss_nce", "loss_intra_nce", "loss_cross_nce", "loss_cross_nce2", "loss_cls", "loss_er", "loss_ecr"):
-                # (step 0: float atomics in the loss sums only; later steps also carry the atomics noise of the weight gradients through the update)
-                assert abs(x[k] - y[k]) <= (2e-6 if j == 0 else 5e-5) * max(1.0, abs(x[k])), (j, k, x[k], y[k])
+                # (step 0: float atomics in the loss sums only; later steps also carry the atomics noise of the weight gradients through the update.  bf16: that
+                #  noise — 1e-7 of a weight — can flip a near-tie decision of the bf16 forward by step 3: two runs of the SAME schedule then land on one of two
+                #  values 3.5e-4 apart (measured in round 3 with round 2's library too: 1.789045 / 1.789672, one run in six), so the later steps of the bf16
+                #  case are held to 1e-3; the prefix being dropped or reused wrongly would move the loss by far more — it changes the whole input)
+                later = 5e-5 if prec != "bf16" else 1e-3
+                assert abs(x[k] - y[k]) <= (2e-6 if j == 0 else later) * max(1.0, abs(x[k])), (j, k, x[k], y[k])
     upd = float((wa - w0).abs().max())
     assert upd > 0 and float((wa - wb).abs().max()) <= 2e-3 * upd, (upd, float((wa - wb).abs().max()))
 
