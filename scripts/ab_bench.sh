@@ -5,7 +5,7 @@ OUT=$1; shift; mkdir -p "$OUT"
 i=0
 for spec in "$@"; do
   i=$((i+1)); name=${spec%%=*}; envs=${spec#*=}
-  env $envs timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --parity-steps 0 > "$OUT/$i.$name.json" 2> "$OUT/$i.$name.err" || { echo "$name failed"; tail -3 "$OUT/$i.$name.err"; exit 1; }
+  env $envs timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras --parity-steps 0 > "$OUT/$i.$name.json" 2> "$OUT/$i.$name.err" || { echo "$name failed"; tail -3 "$OUT/$i.$name.err"; exit 1; }
   python - "$OUT/$i.$name.json" "$name" <<'P'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])

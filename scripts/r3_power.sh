@@ -1,7 +1,7 @@
 #!/bin/bash
 # board power / clocks while the bench runs (ON the GPU box): is the step running at the power cap?
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-python "$ROOT/bench.py" --steps 600 --warmup 5 --no-cpu-baseline --parity-steps 0 > /tmp/bench_power.json 2> /tmp/bench_power.err &
+python "$ROOT/bench.py" --steps 600 --warmup 5 --no-cpu-baseline --no-extras --parity-steps 0 > /tmp/bench_power.json 2> /tmp/bench_power.err &
 BP=$!
 for i in $(seq 1 120); do
   w=$(rocm-smi --showpower 2>/dev/null | grep -i "Power (W)" | sed 's/.*: //' | cut -d. -f1)

@@ -7,13 +7,13 @@ OUT=$ROOT/gpurun_out/refresh
 R=${WSEG_ROUND:-r03}
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -o run -- python "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --parity-steps 0 > "$OUT/pmc_fetch.log" 2>&1 && echo "pmc fetch ok" &&
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -o run -- python "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --parity-steps 0 > "$OUT/pmc_write.log" 2>&1 && echo "pmc write ok" &&
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -o run -- python "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-extras --parity-steps 0 > "$OUT/pmc_fetch.log" 2>&1 && echo "pmc fetch ok" &&
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -o run -- python "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-extras --parity-steps 0 > "$OUT/pmc_write.log" 2>&1 && echo "pmc write ok" &&
 python "$ROOT/scripts/summarize_pmc.py" $(find "$OUT/pmc_fetch" -name run_counter_collection.csv) $(find "$OUT/pmc_write" -name run_counter_collection.csv) "$OUT/${R}_pmc_traffic.json" > "$OUT/pmc_summary.txt" &&
 rm -rf "$OUT/pmc_fetch" "$OUT/pmc_write" &&
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o run -- python "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --parity-steps 0 > "$OUT/stats.log" 2>&1 &&
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o run -- python "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-extras --parity-steps 0 > "$OUT/stats.log" 2>&1 &&
 cp $(find "$OUT/stats" -name run_kernel_stats.csv) "$OUT/${R}_bench_b16_448_bf16_kernel_stats.csv" && rm -rf "$OUT/stats" && echo "stats ok" &&
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats3" -o run -- python "$ROOT/bench.py" --precision bf16x3 --steps 4 --warmup 2 --no-cpu-baseline --parity-steps 0 > "$OUT/stats3.log" 2>&1 &&
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats3" -o run -- python "$ROOT/bench.py" --precision bf16x3 --steps 4 --warmup 2 --no-cpu-baseline --no-extras --parity-steps 0 > "$OUT/stats3.log" 2>&1 &&
 cp $(find "$OUT/stats3" -name run_kernel_stats.csv) "$OUT/${R}_bench_b16_448_bf16x3_kernel_stats.csv" && rm -rf "$OUT/stats3" && echo "stats x3 ok" &&
 cd "$ROOT" &&
 timeout -k 10 300 python scripts/profile_layers.py bf16 > "$OUT/${R}_layers_b16_448_bf16.txt" 2>&1 && echo "layers ok" &&
