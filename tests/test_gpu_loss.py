@@ -167,7 +167,7 @@ def test_gradients_under_the_hip_paths_relu_decisions(golden_dir, proc_sd, name,
 # (b) the arithmetic is held to 1e-4 on ALL 8 scalars by the selection-injected oracle: the CPU oracle re-run with the HIP path's own prototypes
 # and pseudo-labels in place of its own.
 S448_NCE_BAR = 4e-4
-REF_TIE = {"fp32": 1e-4, "bf16x3": 1e-3}     # largest REFERENCE gap at which a selection may differ (bf16x3: ~1e-5 forward deviation, hi.lo products)
+REF_TIE = {"fp32": 1e-4, "bf16x3": 1e-4}     # largest REFERENCE gap at which a selection may differ; measured (profiles/r03_parity_measured.txt): 1.4e-5 in both modes
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16x3"])
