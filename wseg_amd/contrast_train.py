@@ -49,7 +49,8 @@ def main(argv=None):
     parser.add_argument("--precision", default=None, choices=[None, "bf16", "fp32", "bf16x3"])
     parser.add_argument("--rng_parity", action="store_true")
     parser.add_argument("--seed", default=0, type=int)
-    parser.add_argument("--device_augment", action="store_true")
+    parser.add_argument("--device_augment", action="store_true",
+                        help="training augmentation on the GPU (bit-exact against this package's PIL restatement; parity with the reference's torchvision transforms is unpinned: not importable offline)")
     args = parser.parse_args(argv)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -122,7 +123,7 @@ def main(argv=None):
             loader.sampler.set_epoch(ep)
         it = iter(loader) if loader is not None else None
         if aug is not None:
-            it = aug.batches(it)                            # (decode workers -> device augmentation one batch ahead, on a side stream)
+            it = aug.batches(it)                            # (decode workers -> device augmentation on the caller's stream, in front of the step; overlap=True: one batch ahead on a side stream)
         def fetch(itn):
             if itn >= steps_per_epoch:
                 return None
