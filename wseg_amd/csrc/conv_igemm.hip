@@ -994,8 +994,9 @@ __global__ __launch_bounds__(512, 2) void conv_igemm512x128_kernel(const Args a)
   long koff1 = 0, koff2 = 0;                       // tap offset + K offset inside the tap (bytes), per row segment
   const char* bptr = Wp + ((size_t)(n0 + r0) * a.taps * d.IC + (size_t)lc * CH) * ES;   // OC % 128 == 0 (host-checked)
   const int brs = 64 * a.taps * d.IC * ES;
-  auto set_tap = [&](int tap) {
-    const int ky = tap / d.KW, kx = tap - ky * d.KW;
+  int t_ky = 0, t_kx = 0;                          // kernel coordinates of the current tap (taps come in natural order: no division)
+  auto set_tap = [&]() {
+    const int ky = t_ky, kx = t_kx;
     const int dyt = d.mode == 0 ? ky * d.dil : -ky * d.dil, dxt = d.mode == 0 ? kx * d.dil : -kx * d.dil;   // (uniform)
     koff1 = ((long)dyt * d.IW + dxt) * d.ld_in * ES; koff2 = ((long)dyt * d.IW2 + dxt) * d.ld_in * ES;
     a_ok = 0;
@@ -1008,15 +1009,20 @@ __global__ __launch_bounds__(512, 2) void conv_igemm512x128_kernel(const Args a)
     }
   };
   int a_tap = 0, a_cc = 0;
-  auto issue_a = [&](int buf) {                    // the NEXT A tile (8 pieces), then advance
+  auto issue_a = [&](int buf) {                    // the NEXT A tile (8 pieces)
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const char* p = rowptr[j] + (((segmask >> j) & 1u) ? koff2 : koff1);
       p = ((a_ok >> j) & 1u) ? p : zsrc;
       glds16(p, smem + buf * TILE5 + (j >> 1) * HALF256 + (j & 1) * 8192 + wid * 1024);
     }
+  };
+  auto advance_a = [&]() {                         // (called in an MFMA slot whose partner slot is longer — see conv_igemm256_tile: these layers change tap every 1-2 K-tiles)
     koff1 += 128; koff2 += 128;
-    if (++a_cc == a.cpt) { a_cc = 0; if (++a_tap < a.taps) set_tap(a_tap); }
+    if (++a_cc == a.cpt) {
+      a_cc = 0;
+      if (++a_tap < a.taps) { if (++t_kx == d.KW) { t_kx = 0; ++t_ky; } set_tap(); }
+    }
   };
   auto issue_b = [&](int buf) {                    // the NEXT B tile (2 pieces), then advance
     char* dst = smem + buf * TILE5 + 4 * HALF256 + wid * 1024;
@@ -1032,8 +1038,8 @@ __global__ __launch_bounds__(512, 2) void conv_igemm512x128_kernel(const Args a)
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nt = a.taps * a.cpt;
-  set_tap(0);
-  issue_a(0); issue_b(0);
+  set_tap();
+  issue_a(0); advance_a(); issue_b(0);
   if (nt > 1) { issue_b(1); asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -1071,12 +1077,14 @@ __global__ __launch_bounds__(512, 2) void conv_igemm512x128_kernel(const Args a)
         bf[ks][j] = *reinterpret_cast<const bf16x8*>(bH + (wc * 64 + j * 16 + frow) * 128 + (((ks * 4 + fk) ^ sw) << 4));
     if (u + 1 < nt) issue_a(b ^ 1);
     __builtin_amdgcn_s_barrier();
+    if (grp == 0 && u + 1 < nt) advance_a();
     MFMA_H5(0);
     __builtin_amdgcn_s_barrier();
     ldA(aH, 1);
     if (u + 2 < nt) { issue_b(b); asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    if (grp == 1 && u + 1 < nt) advance_a();
     MFMA_H5(1);
     __builtin_amdgcn_s_barrier();
   }
