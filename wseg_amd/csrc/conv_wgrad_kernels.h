@@ -614,7 +614,7 @@ __device__ __forceinline__ void conv_wgrad_pipe_tile(const Args& a, char* smem, 
         tr_read<BO + 0>(vb1[0][0][j], LTB[2 + j]); tr_read<BO + 1024>(vb1[0][1][j], LTB[2 + j]);
         tr_read<BO + 8192>(vb1[1][0][j], LTB[2 + j]); tr_read<BO + 9216>(vb1[1][1][j], LTB[2 + j]);
       }
-      if (u + 1 < nt) { issue_y(0, b ^ 1); issue_y(1, b ^ 1); }
+      if (u + 1 < nt && WG_DIAG(a) != 6) { issue_y(0, b ^ 1); issue_y(1, b ^ 1); }   // (diag 6, probe builds: no LDS-DMA request inside the loop — timing only)
       WAIT_LDS();
       PACK_A() PACK_B(b0, vb0) PACK_B(b1, vb1)
       MFMA_Q(0, 0, b0);
@@ -626,7 +626,7 @@ __device__ __forceinline__ void conv_wgrad_pipe_tile(const Args& a, char* smem, 
         tr_read<BO + 0>(va[0][0][i], LTA[4 + i]); tr_read<BO + 1024>(va[0][1][i], LTA[4 + i]);
         tr_read<BO + 8192>(va[1][0][i], LTA[4 + i]); tr_read<BO + 9216>(va[1][1][i], LTA[4 + i]);
       }
-      if (u + 2 < nt) { x_prepare(); issue_x(0, b); issue_x(1, b); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+      if (u + 2 < nt) { if (WG_DIAG(a) != 6) { x_prepare(); issue_x(0, b); issue_x(1, b); } asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       WAIT_LDS();
       PACK_A()
