@@ -1,5 +1,5 @@
 #!/bin/bash
-# kernel-stats A/B of two builds on one box (runs ON the GPU box): bash scripts/r3_stats_ab.sh OUT "name=ENV" ...
+# kernel-stats A/B of two builds on one box (runs ON the GPU box): bash scripts/ab_kernel_stats.sh OUT "name=ENV" ...
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/$1; shift; rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp

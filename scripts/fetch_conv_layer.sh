@@ -1,5 +1,5 @@
 #!/bin/bash
-# FETCH_SIZE / WRITE_SIZE of one conv layer (ON the GPU box): bash scripts/r3_fetch.sh 512
+# FETCH_SIZE / WRITE_SIZE of one conv layer (ON the GPU box): bash scripts/fetch_conv_layer.sh 512
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 W=${1:-512}; OUT=$ROOT/gpurun_out/fetch_$W; rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp

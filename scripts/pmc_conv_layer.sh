@@ -1,5 +1,5 @@
 #!/bin/bash
-# counter passes over one conv layer (runs ON the GPU box): scripts/gpu.sh 600 'bash scripts/r3_pmc_conv.sh 512 conv_igemm256'
+# counter passes over one conv layer (runs ON the GPU box): scripts/gpu.sh 600 'bash scripts/pmc_conv_layer.sh 512 conv_igemm256'
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 W=${1:-512}; K=${2:-conv_igemm256}; HINT=${3:-0}
 OUT=$ROOT/gpurun_out/pmc_$W; rm -rf "$OUT"; mkdir -p "$OUT"
